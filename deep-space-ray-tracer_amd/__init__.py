@@ -1,0 +1,212 @@
+"""Python plumbing over libdsrt_hip.so (tests, bench and the multi-GPU launcher use it).
+
+The product is the shared library and its C ABI (include/dsrt.h); this package only moves pointers and sizes across
+that boundary.  It is imported as `dsrt_amd` (see dsrt_amd.py at the repository root: the directory name mandated for
+the package contains hyphens and cannot be written in an import statement).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (DsrtFrame, DsrtPose, DsrtRenderDesc, DsrtStats, GPUCamera, GPUScene)
+
+lib = capi.load()
+
+
+class DsrtError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.dsrt_last_error()
+        super().__init__(f"{where} failed with {code}: {msg.decode() if msg else ''}")
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise DsrtError(rc, where)
+
+
+def _f3(v):
+    return (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+class HostScene:
+    """Flattened scene + BVH on the host (DsrtHostScene)."""
+
+    def __init__(self):
+        self._h = lib.dsrt_host_scene_create()
+        self._built = False
+
+    def close(self):
+        if self._h:
+            lib.dsrt_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_obj(self, path, scale=1.0):
+        _check(lib.dsrt_host_scene_add_obj(self._h, str(path).encode(), float(scale)), "dsrt_host_scene_add_obj")
+        self._built = False
+        return self
+
+    def add_world_file(self, path):
+        _check(lib.dsrt_host_scene_add_world_file(self._h, str(path).encode()), "dsrt_host_scene_add_world_file")
+        self._built = False
+        return self
+
+    def add_arrays(self, tris=None, spheres=None, mats=None):
+        def arr(a, dt):
+            a = np.ascontiguousarray(a if a is not None else np.zeros(0, dt), dtype=dt)
+            return a, (a.ctypes.data if a.size else None), int(a.size)
+        t, tp, tn = arr(tris, capi.TRI_DTYPE)
+        s, sp, sn = arr(spheres, capi.SPHERE_DTYPE)
+        m, mp, mn = arr(mats, capi.MAT_DTYPE)
+        _check(lib.dsrt_host_scene_add_arrays(self._h, tp, tn, sp, sn, mp, mn), "dsrt_host_scene_add_arrays")
+        self._built = False
+        return self
+
+    def build_bvh(self):
+        _check(lib.dsrt_host_scene_build_bvh(self._h), "dsrt_host_scene_build_bvh")
+        self._built = True
+        return self
+
+    @property
+    def stack_need(self):
+        return lib.dsrt_host_scene_bvh_stack_need(self._h)
+
+    def view(self, camera=None, sun_dir=None):
+        """GPUScene with HOST pointers (valid while this object lives and is not modified)."""
+        if not self._built:
+            self.build_bvh()
+        s = GPUScene()
+        _check(lib.dsrt_host_scene_view(self._h, C.byref(s)), "dsrt_host_scene_view")
+        if camera is not None:
+            lib.dsrt_scene_set_frame(C.byref(s), C.byref(camera), _f3(sun_dir if sun_dir is not None else (0.0, -1.0, 0.0)))
+        return s
+
+    def arrays(self):
+        """numpy copies of the flattened arrays, in the reference layouts."""
+        s = self.view()
+
+        def grab(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+        return {
+            "tris": grab(s.triangles, s.num_triangles, capi.TRI_DTYPE),
+            "spheres": grab(s.spheres, s.num_spheres, capi.SPHERE_DTYPE),
+            "mats": grab(s.materials, s.num_materials, capi.MAT_DTYPE),
+            "idx": grab(s.tri_indices, s.num_triangles if s.tri_indices else 0, np.dtype("<i4")),
+            "nodes": grab(s.bvh_nodes, s.num_bvh_nodes, capi.NODE_DTYPE),
+            "texhdr": grab(s.textures, s.num_textures, capi.TEXHDR_DTYPE),
+            "texpool": grab(s.texture_pool, s.texture_pool_floats, np.dtype("<f4")),
+        }
+
+
+def read_pose_file(path):
+    n = C.c_int(0)
+    rc = lib.dsrt_read_pose_file(str(path).encode(), None, 0, C.byref(n))
+    _check(rc, "dsrt_read_pose_file")
+    poses = (DsrtPose * n.value)()
+    _check(lib.dsrt_read_pose_file(str(path).encode(), poses, n.value, C.byref(n)), "dsrt_read_pose_file")
+    return list(poses)
+
+
+def pose_to_frame(pose):
+    f = DsrtFrame()
+    _check(lib.dsrt_pose_to_frame(C.byref(pose), C.byref(f)), "dsrt_pose_to_frame")
+    return f
+
+
+def camera_look_at(lookfrom, lookat, vfov, width, height, spp, max_depth):
+    cam = GPUCamera()
+    _check(lib.dsrt_camera_look_at(C.byref(cam), _f3(lookfrom), _f3(lookat), float(vfov), int(width), int(height), int(spp), int(max_depth)),
+           "dsrt_camera_look_at")
+    return cam
+
+
+def frame_camera(frame, vfov, width, height, spp, max_depth):
+    """Camera for one pose frame: at cam_in_model, looking at the model origin (src/main.cpp:399)."""
+    return camera_look_at(tuple(frame.cam_in_model), (0.0, 0.0, 0.0), vfov, width, height, spp, max_depth)
+
+
+def write_ppm(path, rgb, width, height):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _check(lib.dsrt_write_ppm(str(path).encode(), rgb.ctypes.data, int(width), int(height)), "dsrt_write_ppm")
+
+
+def make_desc(width, height, spp, max_depth=50, gamma=2.0, seed=1337, tile_size=0, shard_rank=0, shard_count=0,
+              collect_counters=0, checked=0, stack_entries=0):
+    d = DsrtRenderDesc()
+    d.width, d.height, d.spp, d.max_depth, d.gamma, d.seed = int(width), int(height), int(spp), int(max_depth), float(gamma), int(seed)
+    d.rng_mode = 0
+    d.tile_size, d.shard_rank, d.shard_count = int(tile_size), int(shard_rank), int(shard_count)
+    d.collect_counters, d.checked, d.stack_entries = int(collect_counters), int(checked), int(stack_entries)
+    return d
+
+
+def shard_layout(desc):
+    total, mine, padded, nbytes = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    _check(lib.dsrt_shard_layout(C.byref(desc), C.byref(total), C.byref(mine), C.byref(padded), C.byref(nbytes)), "dsrt_shard_layout")
+    return {"tiles_total": total.value, "tiles_this_shard": mine.value, "tiles_per_shard_padded": padded.value, "rgb8_bytes_padded": nbytes.value}
+
+
+def stats_dict(st):
+    return {name: getattr(st, name) for name, _ in DsrtStats._fields_}
+
+
+class Context:
+    """One GPU: resident scene in traversal layout + render launches (DsrtContext)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib.dsrt_ctx_create(int(device), C.byref(h)), "dsrt_ctx_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dsrt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, scene_host_view):
+        _check(lib.dsrt_scene_upload(self._h, C.byref(scene_host_view)), "dsrt_scene_upload")
+
+    def upload_device(self, scene_device_view):
+        _check(lib.dsrt_scene_upload_device(self._h, C.byref(scene_device_view)), "dsrt_scene_upload_device")
+
+    def set_camera_sun(self, camera, sun_dir):
+        _check(lib.dsrt_scene_set_camera_sun(self._h, C.byref(camera), _f3(sun_dir)), "dsrt_scene_set_camera_sun")
+
+    def render(self, desc, d_rgb8_ptr, d_f32_ptr=None, stream=None, want_stats=False):
+        """Launch on `stream` (raw hipStream_t as int); with want_stats the call synchronises and returns DsrtStats."""
+        st = DsrtStats() if want_stats else None
+        rc = lib.dsrt_render(self._h, C.byref(desc), C.c_void_p(d_rgb8_ptr), C.c_void_p(d_f32_ptr) if d_f32_ptr else None,
+                             C.c_void_p(stream) if stream else None, C.byref(st) if st is not None else None)
+        _check(rc, "dsrt_render")
+        return st
+
+    def deinterleave(self, desc, d_gathered_ptr, d_image_ptr, stream=None):
+        _check(lib.dsrt_deinterleave_tiles(self._h, C.byref(desc), C.c_void_p(d_gathered_ptr), C.c_void_p(d_image_ptr),
+                                           C.c_void_p(stream) if stream else None), "dsrt_deinterleave_tiles")
+
+    def render_to_host(self, desc, want_f32=False):
+        n = desc.width * desc.height * 3
+        rgb = np.zeros(n, np.uint8)
+        f32 = np.zeros(n, np.float32) if want_f32 else None
+        st = DsrtStats()
+        rc = lib.dsrt_render_to_host(self._h, C.byref(desc), rgb.ctypes.data, f32.ctypes.data if want_f32 else None, C.byref(st))
+        _check(rc, "dsrt_render_to_host")
+        shape = (desc.height, desc.width, 3)
+        return rgb.reshape(shape), (f32.reshape(shape) if want_f32 else None), st
+
+    def selftest_math(self, fn, x, y=0.0):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(x)
+        _check(lib.dsrt_selftest_math(self._h, int(fn), x.ctypes.data, float(y), out.ctypes.data, int(x.size)), "dsrt_selftest_math")
+        return out

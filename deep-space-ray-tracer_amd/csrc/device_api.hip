@@ -1,0 +1,570 @@
+// device_api.hip -- the device half of the C ABI (include/dsrt.h): context, scene upload + re-layout,
+// render launch, tile de-interleave, and the reference's own entry points on top of them.
+//
+// Replaces: the cudaMalloc/cudaMemcpy half of build_gpu_scene (src/gpu_scene_builder.cpp:322-331, 475-546),
+// free_gpu_scene (:603-626) and the host launcher gpu_render_scene (src/gpu_render.cu:1037-1108).
+// Differences by design: the scene is converted once into the traversal layout of device_layout.h and stays
+// resident across frames (the reference re-uploads everything per frame, src/main.cpp:405); errors are returned,
+// not only printed; the launch is asynchronous on a caller-supplied stream; output goes to caller-owned buffers.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dsrt.h"
+#include "../host/host_internal.hpp"
+#include "device_layout.h"
+
+namespace dsrt {
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
+                               size_t shard_stride_bytes, hipStream_t stream);
+hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
+int kernel_waves_per_block();
+}  // namespace dsrt
+
+using namespace dsrt;
+
+namespace {
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(expr) do { if (!hip_ok((expr), #expr)) return DSRT_ERR_HIP; } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { reset(); }
+    void reset() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    int upload(const std::vector<T>& v) {
+        reset();
+        if (v.empty()) return DSRT_OK;
+        HIP_TRY(hipMalloc((void**)&p, v.size() * sizeof(T)));
+        n = v.size();
+        HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return DSRT_OK;
+    }
+    int alloc(size_t count) {
+        reset();
+        if (!count) return DSRT_OK;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return DSRT_OK;
+    }
+};
+
+// The scene in traversal layout, owning its device memory.
+struct PackedScene {
+    DevBuf<float4> pairs, tri_isect, tri_shade, tri_uv, materials;
+    DevBuf<int2> big_leaves;
+    DevBuf<GPUSphere> spheres;
+    DevBuf<GPUTextureHeader> tex_headers;
+    DevBuf<float> tex_pool;
+    DeviceScene view{};
+    GPUCamera camera{};
+    DsrtF3 sun_dir{}, sun_radiance{};
+    int sun_enabled = 0;
+    bool valid = false;
+};
+
+float4 as_f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+float bits(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+// Host-side conversion of reference-layout arrays into the traversal layout.  Validates every index the kernel
+// will follow, so the fast (unchecked) kernel build never sees an out-of-range reference.
+int pack_scene(const GPUScene& h, PackedScene& out) {
+    const int N = h.num_triangles, M = h.num_bvh_nodes;
+    if (N < 0 || M < 0 || h.num_spheres < 0 || h.num_materials < 0 || h.num_textures < 0 || h.texture_pool_floats < 0) {
+        set_error("scene has a negative count"); return DSRT_ERR_INVALID;
+    }
+    if ((N && !h.triangles) || (h.num_spheres && !h.spheres) || (h.num_materials && !h.materials)) { set_error("scene array pointer is null"); return DSRT_ERR_INVALID; }
+    if (N > (1 << 28)) { set_error("more than 2^28 triangles"); return DSRT_ERR_INVALID; }
+    const bool has_bvh = h.bvh_nodes && M > 0 && h.tri_indices;        // bvh_hit_closest's own guard, src/gpu_render.cu:394-397
+    for (int i = 0; i < N; ++i) if (h.triangles[i].material_id < 0 || h.triangles[i].material_id >= h.num_materials) { set_error("triangle material id out of range"); return DSRT_ERR_INVALID; }
+    for (int i = 0; i < h.num_spheres; ++i) if (h.spheres[i].material_id < 0 || h.spheres[i].material_id >= h.num_materials) { set_error("sphere material id out of range"); return DSRT_ERR_INVALID; }
+
+    std::vector<float4> pairs, isect, shade, uv, mats;
+    std::vector<int2> big;
+    DeviceScene& v = out.view;
+    std::memset(&v, 0, sizeof v);
+    v.root_ref = kRefNone;
+
+    if (has_bvh) {
+        for (int i = 0; i < N; ++i) if (h.tri_indices[i] < 0 || h.tri_indices[i] >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
+        // internal node -> slot in `pairs`, assigned in a depth-first walk from the root (also detects cycles / sharing)
+        std::vector<int> slot_of(M, -1);
+        std::vector<char> seen(M, 0);
+        struct Item { int node; int internal_above; };
+        std::vector<Item> todo{{0, 0}};
+        int stack_need = 0;
+        std::vector<int> order;                                          // internal nodes in visiting order
+        while (!todo.empty()) {
+            Item it = todo.back(); todo.pop_back();
+            if (it.node < 0 || it.node >= M) { set_error("BVH child index out of range"); return DSRT_ERR_INVALID; }
+            if (seen[it.node]) { set_error("BVH is not a tree (node reached twice)"); return DSRT_ERR_INVALID; }
+            seen[it.node] = 1;
+            const GPUBVHNode& n = h.bvh_nodes[it.node];
+            if (n.tri_count > 0) {
+                if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
+                if (it.internal_above > stack_need) stack_need = it.internal_above;
+            } else {
+                slot_of[it.node] = (int)order.size();
+                order.push_back(it.node);
+                todo.push_back({n.right, it.internal_above + 1});
+                todo.push_back({n.left, it.internal_above + 1});
+            }
+        }
+        if (stack_need > 64) { set_error("BVH needs a traversal stack deeper than the reference's 64 entries"); return DSRT_ERR_BVH_DEPTH; }
+        auto ref_of = [&](int node) -> int {
+            const GPUBVHNode& n = h.bvh_nodes[node];
+            if (n.tri_count <= 0) return slot_of[node];
+            if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, n.tri_offset);
+            big.push_back(make_int2(n.tri_offset, n.tri_count));
+            return make_leaf_ref(7, (int)big.size() - 1);
+        };
+        pairs.resize(order.size() * 4);
+        for (size_t s = 0; s < order.size(); ++s) {
+            const GPUBVHNode& n = h.bvh_nodes[order[s]];
+            const GPUBVHNode& l = h.bvh_nodes[n.left];
+            const GPUBVHNode& r = h.bvh_nodes[n.right];
+            pairs[4 * s + 0] = as_f4(l.bbox_min.x, l.bbox_min.y, l.bbox_min.z, l.bbox_max.x);
+            pairs[4 * s + 1] = as_f4(l.bbox_max.y, l.bbox_max.z, r.bbox_min.x, r.bbox_min.y);
+            pairs[4 * s + 2] = as_f4(r.bbox_min.z, r.bbox_max.x, r.bbox_max.y, r.bbox_max.z);
+            pairs[4 * s + 3] = as_f4(bits(ref_of(n.left)), bits(ref_of(n.right)), 0.0f, 0.0f);
+        }
+        const GPUBVHNode& root = h.bvh_nodes[0];
+        v.root_lo[0] = root.bbox_min.x; v.root_lo[1] = root.bbox_min.y; v.root_lo[2] = root.bbox_min.z;
+        v.root_hi[0] = root.bbox_max.x; v.root_hi[1] = root.bbox_max.y; v.root_hi[2] = root.bbox_max.z;
+        v.root_ref = ref_of(0);
+        v.stack_need = stack_need;
+
+        const bool textured = h.num_textures > 0 && h.textures && h.texture_pool;
+        isect.resize((size_t)N * 3);
+        shade.resize((size_t)N * 3);
+        if (textured) uv.resize((size_t)N * 2);
+        for (int j = 0; j < N; ++j) {
+            const int src = h.tri_indices[j];
+            const GPUTriangle& t = h.triangles[src];
+            const float e1x = t.v1.x - t.v0.x, e1y = t.v1.y - t.v0.y, e1z = t.v1.z - t.v0.z;
+            const float e2x = t.v2.x - t.v0.x, e2y = t.v2.y - t.v0.y, e2z = t.v2.z - t.v0.z;
+            isect[3 * (size_t)j + 0] = as_f4(t.v0.x, t.v0.y, t.v0.z, e1x);
+            isect[3 * (size_t)j + 1] = as_f4(e1y, e1z, e2x, e2y);
+            isect[3 * (size_t)j + 2] = as_f4(e2z, 0.0f, 0.0f, 0.0f);
+            shade[3 * (size_t)j + 0] = as_f4(t.n0.x, t.n0.y, t.n0.z, t.n1.x);
+            shade[3 * (size_t)j + 1] = as_f4(t.n1.y, t.n1.z, t.n2.x, t.n2.y);
+            shade[3 * (size_t)j + 2] = as_f4(t.n2.z, bits(t.material_id), bits(t.albedo_tex), bits(src));
+            if (textured) {
+                uv[2 * (size_t)j + 0] = as_f4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
+                uv[2 * (size_t)j + 1] = as_f4(t.uv2.x, t.uv2.y, 0.0f, 0.0f);
+            }
+        }
+    }
+    mats.resize((size_t)h.num_materials * 3);
+    for (int i = 0; i < h.num_materials; ++i) {
+        const GPUMaterial& m = h.materials[i];
+        mats[3 * (size_t)i + 0] = as_f4(bits(m.type), bits(m.albedo_tex), 0.0f, 0.0f);
+        mats[3 * (size_t)i + 1] = as_f4(m.albedo.x, m.albedo.y, m.albedo.z, m.emissive.x);
+        mats[3 * (size_t)i + 2] = as_f4(m.emissive.y, m.emissive.z, m.fuzz, m.ref_idx);
+    }
+    int num_lights = 0;                                                   // src/gpu_render.cu:841-847, a scene constant
+    for (int i = 0; i < h.num_spheres; ++i) {
+        const GPUMaterial& lm = h.materials[h.spheres[i].material_id];
+        if (lm.type == MAT_DIFFUSE_LIGHT && (lm.emissive.x > 0 || lm.emissive.y > 0 || lm.emissive.z > 0)) num_lights++;
+    }
+    if (h.num_textures > 0 && h.textures && h.texture_pool) {
+        for (int i = 0; i < h.num_textures; ++i) {
+            const GPUTextureHeader& th = h.textures[i];
+            if (th.width < 1 || th.height < 1 || th.offset < 0) { set_error("texture header out of range"); return DSRT_ERR_INVALID; }
+        }
+    }
+
+    int rc;
+    if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_isect.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
+        (rc = out.tri_uv.upload(uv)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
+    std::vector<GPUSphere> sph(h.spheres, h.spheres + h.num_spheres);
+    if ((rc = out.spheres.upload(sph))) return rc;
+    if (h.num_textures > 0 && h.textures && h.texture_pool) {
+        std::vector<GPUTextureHeader> th(h.textures, h.textures + h.num_textures);
+        std::vector<float> pool(h.texture_pool, h.texture_pool + h.texture_pool_floats);
+        if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
+    } else { out.tex_headers.reset(); out.tex_pool.reset(); }
+
+    v.pairs = out.pairs.p; v.tri_isect = out.tri_isect.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
+    v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
+    v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
+    v.num_pairs = (int)(pairs.size() / 4); v.num_tris = has_bvh ? N : 0; v.num_big_leaves = (int)big.size();
+    v.num_materials = h.num_materials; v.num_spheres = h.num_spheres; v.num_lights = num_lights;
+    v.num_textures = (int)out.tex_headers.n; v.tex_pool_floats = (int)out.tex_pool.n;
+    out.camera = h.camera;
+    out.sun_dir = h.sun_dir; out.sun_radiance = h.sun_radiance; out.sun_enabled = h.sun_enabled ? 1 : 0;
+    out.valid = true;
+    return DSRT_OK;
+}
+
+}  // namespace
+
+struct DsrtContext {
+    int device = 0;
+    int num_cus = 0;
+    PackedScene scene;
+    DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
+    DevBuf<uint2> spill;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+};
+
+namespace {
+
+constexpr size_t kCtrlWords = 4 + 2 * (size_t)kNumCounters;
+
+struct Tiling { int tile, tiles_x, tiles_y, total, mine, padded; };
+bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
+    t.tile = d.tile_size > 0 ? d.tile_size : 8;
+    if (t.tile % 8 != 0 || t.tile > 1024 || d.width < 2 || d.height < 2) return false;
+    const int count = d.shard_count > 1 ? d.shard_count : 1;
+    if (d.shard_rank < 0 || d.shard_rank >= count) return false;
+    t.tiles_x = (d.width + t.tile - 1) / t.tile;
+    t.tiles_y = (d.height + t.tile - 1) / t.tile;
+    t.total = t.tiles_x * t.tiles_y;
+    t.mine = (t.total - d.shard_rank + count - 1) / count;
+    t.padded = (t.total + count - 1) / count;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dsrt_ctx_create(int device, DsrtContext** out) {
+    if (!out) { set_error("dsrt_ctx_create: null out"); return DSRT_ERR_INVALID; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return DSRT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { set_error("device index out of range"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+        return DSRT_ERR_NO_DEVICE;
+    }
+    auto* ctx = new DsrtContext();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    int rc = ctx->ctrl.alloc(kCtrlWords);
+    if (rc) { delete ctx; return rc; }
+    if (!hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate")) { delete ctx; return DSRT_ERR_HIP; }
+    *out = ctx;
+    return DSRT_OK;
+}
+
+void dsrt_ctx_destroy(DsrtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    delete ctx;
+}
+
+int dsrt_scene_upload(DsrtContext* ctx, const GPUScene* scene) {
+    if (!ctx || !scene) { set_error("dsrt_scene_upload: null argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->scene.valid = false;
+    return pack_scene(*scene, ctx->scene);
+}
+
+int dsrt_scene_upload_device(DsrtContext* ctx, const GPUScene* d) {
+    if (!ctx || !d) { set_error("dsrt_scene_upload_device: null argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (d->num_triangles < 0 || d->num_spheres < 0 || d->num_materials < 0 || d->num_bvh_nodes < 0 || d->num_textures < 0 || d->texture_pool_floats < 0) {
+        set_error("scene has a negative count"); return DSRT_ERR_INVALID;
+    }
+    // Bring the reference-layout arrays back to the host, then convert as usual.
+    std::vector<GPUTriangle> tris((size_t)(d->triangles ? d->num_triangles : 0));
+    std::vector<GPUSphere> sph((size_t)(d->spheres ? d->num_spheres : 0));
+    std::vector<GPUMaterial> mats((size_t)(d->materials ? d->num_materials : 0));
+    std::vector<int> idx((size_t)(d->tri_indices ? d->num_triangles : 0));
+    std::vector<GPUBVHNode> nodes((size_t)(d->bvh_nodes ? d->num_bvh_nodes : 0));
+    std::vector<GPUTextureHeader> th((size_t)(d->textures ? d->num_textures : 0));
+    std::vector<float> pool((size_t)(d->texture_pool ? d->texture_pool_floats : 0));
+    auto pull = [](void* dst, const void* src, size_t bytes) { return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess; };
+    HIP_TRY(pull(tris.data(), d->triangles, tris.size() * sizeof(GPUTriangle)));
+    HIP_TRY(pull(sph.data(), d->spheres, sph.size() * sizeof(GPUSphere)));
+    HIP_TRY(pull(mats.data(), d->materials, mats.size() * sizeof(GPUMaterial)));
+    HIP_TRY(pull(idx.data(), d->tri_indices, idx.size() * sizeof(int)));
+    HIP_TRY(pull(nodes.data(), d->bvh_nodes, nodes.size() * sizeof(GPUBVHNode)));
+    HIP_TRY(pull(th.data(), d->textures, th.size() * sizeof(GPUTextureHeader)));
+    HIP_TRY(pull(pool.data(), d->texture_pool, pool.size() * sizeof(float)));
+    GPUScene h = *d;
+    h.triangles = tris.empty() ? nullptr : tris.data();
+    h.spheres = sph.empty() ? nullptr : sph.data();
+    h.materials = mats.empty() ? nullptr : mats.data();
+    h.tri_indices = idx.empty() ? nullptr : idx.data();
+    h.bvh_tri_indices = const_cast<int*>(h.tri_indices);
+    h.bvh_nodes = nodes.empty() ? nullptr : nodes.data();
+    h.textures = th.empty() ? nullptr : th.data();
+    h.texture_pool = pool.empty() ? nullptr : pool.data();
+    ctx->scene.valid = false;
+    return pack_scene(h, ctx->scene);
+}
+
+int dsrt_scene_set_camera_sun(DsrtContext* ctx, const GPUCamera* cam, const float sun_dir_model[3]) {
+    if (!ctx || !cam) { set_error("dsrt_scene_set_camera_sun: null argument"); return DSRT_ERR_INVALID; }
+    if (!ctx->scene.valid) { set_error("no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    ctx->scene.camera = *cam;
+    if (sun_dir_model) ctx->scene.sun_dir = DsrtF3{sun_dir_model[0], sun_dir_model[1], sun_dir_model[2]};
+    return DSRT_OK;
+}
+
+int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_this_shard, int* tiles_per_shard_padded, size_t* rgb8_bytes_padded) {
+    Tiling t;
+    if (!desc || !make_tiling(*desc, t)) { set_error("dsrt_shard_layout: bad descriptor"); return DSRT_ERR_INVALID; }
+    if (tiles_total) *tiles_total = t.total;
+    if (tiles_this_shard) *tiles_this_shard = t.mine;
+    if (tiles_per_shard_padded) *tiles_per_shard_padded = t.padded;
+    if (rgb8_bytes_padded) *rgb8_bytes_padded = (size_t)t.padded * t.tile * t.tile * 3;
+    return DSRT_OK;
+}
+
+int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream_v, DsrtStats* stats) {
+    if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
+    if (!ctx->scene.valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    if (desc->rng_mode != 0) { set_error("dsrt_render: only rng_mode 0 (reference LCG stream) is implemented"); return DSRT_ERR_INVALID; }
+    Tiling t;
+    if (!make_tiling(*desc, t)) { set_error("dsrt_render: bad size, tile or shard"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const PackedScene& sc = ctx->scene;
+
+    RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scene = sc.view;
+    FrameParams& f = a.frame;
+    const GPUCamera& c = sc.camera;
+    f.cam_origin[0] = c.origin.x; f.cam_origin[1] = c.origin.y; f.cam_origin[2] = c.origin.z;
+    f.cam_llc[0] = c.lower_left_corner.x; f.cam_llc[1] = c.lower_left_corner.y; f.cam_llc[2] = c.lower_left_corner.z;
+    f.cam_horizontal[0] = c.horizontal.x; f.cam_horizontal[1] = c.horizontal.y; f.cam_horizontal[2] = c.horizontal.z;
+    f.cam_vertical[0] = c.vertical.x; f.cam_vertical[1] = c.vertical.y; f.cam_vertical[2] = c.vertical.z;
+    f.sun_dir[0] = sc.sun_dir.x; f.sun_dir[1] = sc.sun_dir.y; f.sun_dir[2] = sc.sun_dir.z;
+    f.sun_radiance[0] = sc.sun_radiance.x; f.sun_radiance[1] = sc.sun_radiance.y; f.sun_radiance[2] = sc.sun_radiance.z;
+    f.sun_enabled = sc.sun_enabled;
+    f.width = desc->width; f.height = desc->height;
+    f.spp = desc->spp < 1 ? 1 : desc->spp;                              // src/gpu_render.cu:987-988
+    f.max_depth = desc->max_depth > 0 ? desc->max_depth : 12;           // :723-725
+    const float gamma = desc->gamma > 0.0f ? desc->gamma : 1.0f;        // :1043
+    f.inv_gamma = 1.0f / gamma;
+    f.seed32 = (uint32_t)(desc->seed & 0xFFFFFFFFu);
+    f.tile = t.tile; f.tiles_x = t.tiles_x; f.tiles_y = t.tiles_y;
+    f.shard_rank = desc->shard_rank; f.shard_count = desc->shard_count > 1 ? desc->shard_count : 1;
+    f.local_tiles = t.mine;
+    f.total_items = (uint32_t)t.mine * (uint32_t)(t.tile * t.tile);
+    f.compact_output = desc->shard_count > 1 ? 1 : 0;
+    a.out_rgb8 = d_rgb8;
+    a.out_f32 = d_f32;
+    a.queue = ctx->ctrl.p;
+    a.flags = ctx->ctrl.p + 1;
+    a.counters = (uint64_t*)(ctx->ctrl.p + 4);
+
+    // LDS short-stack size: what the BVH can need, capped at the default; the rest spills.
+    int K = desc->stack_entries > 0 ? desc->stack_entries : 12;
+    if (K != 8 && K != 12 && K != 16 && K != 24) { set_error("dsrt_render: stack_entries must be 8, 12, 16 or 24"); return DSRT_ERR_INVALID; }
+    if (desc->stack_entries <= 0 && sc.view.stack_need <= 8) K = 8;
+
+    const int threads_per_block = 64 * kernel_waves_per_block();
+    int blocks = ctx->num_cus * 8;
+    const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
+    if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
+    const int spill_entries = sc.view.stack_need > K ? sc.view.stack_need - K : 0;
+    const size_t lanes = (size_t)blocks * threads_per_block;
+    if (spill_entries > 0 && ctx->spill.n < lanes * (size_t)spill_entries) {
+        int rc = ctx->spill.alloc(lanes * (size_t)spill_entries);
+        if (rc) return rc;
+    }
+    a.spill = ctx->spill.p;
+    a.spill_stride = (uint32_t)lanes;
+    a.spill_entries = spill_entries;
+
+    HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
+    if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    const bool count = desc->collect_counters != 0;
+    HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    if (stats) {
+        HIP_TRY(hipEventRecord(ctx->ev1, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::memset(stats, 0, sizeof *stats);
+        HIP_TRY(hipEventElapsedTime(&stats->kernel_ms, ctx->ev0, ctx->ev1));
+        uint32_t ctrl[kCtrlWords];
+        HIP_TRY(hipMemcpy(ctrl, ctx->ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost));
+        stats->device_flags = ctrl[1];
+        stats->waves_launched = blocks * kernel_waves_per_block();
+        stats->lds_stack_entries = K;
+        uint64_t cnt[kNumCounters];
+        std::memcpy(cnt, &ctrl[4], sizeof cnt);
+        stats->samples = cnt[C_SAMPLES]; stats->rays = cnt[C_RAYS]; stats->primary_hits = cnt[C_PRIMARY_HITS];
+        stats->box_fetches = cnt[C_BOX_FETCHES]; stats->nodes_entered = cnt[C_NODES_ENTERED]; stats->internal_entered = cnt[C_INTERNAL_ENTERED];
+        stats->tri_tests = cnt[C_TRI_TESTS]; stats->hit_updates = cnt[C_HIT_UPDATES]; stats->sphere_tests = cnt[C_SPHERE_TESTS];
+        stats->shaded_hits = cnt[C_SHADED_HITS]; stats->tex_fetches = cnt[C_TEX_FETCHES]; stats->stack_spills = cnt[C_STACK_SPILLS];
+        stats->max_stack = cnt[C_MAX_STACK];
+        if (stats->device_flags) {
+            char buf[96];
+            std::snprintf(buf, sizeof buf, "render kernel raised status flags 0x%x", stats->device_flags);
+            set_error(buf);
+            return DSRT_ERR_DEVICE_FLAG;
+        }
+    }
+    return DSRT_OK;
+}
+
+int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image, void* stream) {
+    Tiling t;
+    if (!ctx || !desc || !d_gathered || !d_rgb8_image || !make_tiling(*desc, t)) { set_error("dsrt_deinterleave_tiles: bad argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int count = desc->shard_count > 1 ? desc->shard_count : 1;
+    HIP_TRY(launch_deinterleave(d_gathered, d_rgb8_image, desc->width, desc->height, t.tile, t.tiles_x, count, (size_t)t.padded * t.tile * t.tile * 3,
+                                (hipStream_t)stream));
+    return DSRT_OK;
+}
+
+int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h_rgb8, float* h_f32, DsrtStats* stats) {
+    if (!ctx || !desc || !h_rgb8) { set_error("dsrt_render_to_host: null argument"); return DSRT_ERR_INVALID; }
+    if (desc->shard_count > 1) { set_error("dsrt_render_to_host renders whole images only"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t px = (size_t)desc->width * desc->height;
+    DevBuf<uint8_t> d8;
+    DevBuf<float> d32;
+    int rc = d8.alloc(px * 3);
+    if (rc) return rc;
+    if (h_f32 && (rc = d32.alloc(px * 3))) return rc;
+    DsrtStats local;
+    rc = dsrt_render(ctx, desc, d8.p, d32.p, nullptr, stats ? stats : &local);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h_rgb8, d8.p, px * 3, hipMemcpyDeviceToHost));
+    if (h_f32) HIP_TRY(hipMemcpy(h_f32, d32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return DSRT_OK;
+}
+
+int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n) {
+    if (!ctx || !x || !out || n <= 0 || fn < 0 || fn > 2) { set_error("dsrt_selftest_math: bad argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<float> dx, dy;
+    int rc;
+    if ((rc = dx.alloc((size_t)n)) || (rc = dy.alloc((size_t)n))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(launch_math(fn, dx.p, y, dy.p, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dy.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return DSRT_OK;
+}
+
+// =========================================================================================
+// Drop-in layer
+// =========================================================================================
+namespace {
+std::mutex g_dropin_mutex;
+DsrtContext* g_dropin_ctx = nullptr;
+
+DsrtContext* dropin_context() {
+    if (!g_dropin_ctx) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        if (dsrt_ctx_create(dev, &g_dropin_ctx) != DSRT_OK) return nullptr;
+    }
+    return g_dropin_ctx;
+}
+}  // namespace
+
+int dsrt_build_gpu_scene(const DsrtHostScene* hs, const GPUCamera* cam, const float sun_dir_model[3], GPUScene* out) {
+    if (!hs || !cam || !out) { set_error("dsrt_build_gpu_scene: null argument"); return DSRT_ERR_INVALID; }
+    GPUScene h;
+    int rc = dsrt_host_scene_view(hs, &h);
+    if (rc) return rc;
+    dsrt_scene_set_frame(&h, cam, sun_dir_model);
+    // The returned header carries DEVICE arrays in the reference layouts, like the reference's own builder.
+    GPUScene d = h;
+    auto push = [&](const void* src, size_t bytes, void** dst) -> int {
+        *dst = nullptr;
+        if (!bytes) return DSRT_OK;
+        HIP_TRY(hipMalloc(dst, bytes));
+        HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return DSRT_OK;
+    };
+    void* p = nullptr;
+    if ((rc = push(h.triangles, (size_t)h.num_triangles * sizeof(GPUTriangle), &p))) return rc; d.triangles = (const GPUTriangle*)p;
+    if ((rc = push(h.spheres, (size_t)h.num_spheres * sizeof(GPUSphere), &p))) return rc; d.spheres = (const GPUSphere*)p;
+    if ((rc = push(h.materials, (size_t)h.num_materials * sizeof(GPUMaterial), &p))) return rc; d.materials = (const GPUMaterial*)p;
+    if ((rc = push(h.tri_indices, (size_t)(h.tri_indices ? h.num_triangles : 0) * sizeof(int), &p))) return rc; d.tri_indices = (const int*)p; d.bvh_tri_indices = (int*)p;
+    if ((rc = push(h.bvh_nodes, (size_t)h.num_bvh_nodes * sizeof(GPUBVHNode), &p))) return rc; d.bvh_nodes = (GPUBVHNode*)p;
+    if ((rc = push(h.textures, (size_t)h.num_textures * sizeof(GPUTextureHeader), &p))) return rc; d.textures = (const GPUTextureHeader*)p;
+    if ((rc = push(h.texture_pool, (size_t)h.texture_pool_floats * sizeof(float), &p))) return rc; d.texture_pool = (const float*)p;
+    *out = d;
+    return DSRT_OK;
+}
+
+void dsrt_free_gpu_scene(GPUScene* s) {                                  // src/gpu_scene_builder.cpp:603-626
+    if (!s) return;
+    if (s->triangles) (void)hipFree((void*)s->triangles);
+    if (s->spheres) (void)hipFree((void*)s->spheres);
+    if (s->materials) (void)hipFree((void*)s->materials);
+    if (s->bvh_nodes) (void)hipFree((void*)s->bvh_nodes);
+    if (s->tri_indices) (void)hipFree((void*)s->tri_indices);
+    if (s->textures) (void)hipFree((void*)s->textures);
+    if (s->texture_pool) (void)hipFree((void*)s->texture_pool);
+    s->triangles = nullptr; s->num_triangles = 0;
+    s->spheres = nullptr; s->num_spheres = 0;
+    s->materials = nullptr; s->num_materials = 0;
+    s->bvh_nodes = nullptr; s->num_bvh_nodes = 0;
+    s->tri_indices = nullptr; s->bvh_tri_indices = nullptr;
+    s->textures = nullptr; s->num_textures = 0;
+    s->texture_pool = nullptr; s->texture_pool_floats = 0;
+}
+
+void gpu_render_scene(const GPUScene* scene, int width, int height) {
+    std::lock_guard<std::mutex> lock(g_dropin_mutex);
+    if (!scene) { std::fprintf(stderr, "gpu_render_scene: null scene\n"); return; }
+    DsrtContext* ctx = dropin_context();
+    if (!ctx) { std::fprintf(stderr, "gpu_render_scene: %s\n", dsrt_last_error()); return; }
+    if (dsrt_scene_upload_device(ctx, scene) != DSRT_OK) { std::fprintf(stderr, "gpu_render_scene: scene upload failed: %s\n", dsrt_last_error()); return; }
+    DsrtRenderDesc d;
+    std::memset(&d, 0, sizeof d);
+    d.width = width; d.height = height;
+    d.spp = scene->params.samples_per_pixel;
+    d.max_depth = scene->params.max_depth;
+    d.gamma = scene->params.gamma;
+    d.seed = scene->seed;
+    std::vector<uint8_t> fb((size_t)width * height * 3);
+    if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, nullptr) != DSRT_OK) { std::fprintf(stderr, "render_kernel failed: %s\n", dsrt_last_error()); return; }
+    if (dsrt_write_ppm("image_gpu.ppm", fb.data(), width, height) != DSRT_OK) std::fprintf(stderr, "Failed to open image_gpu.ppm for writing\n");
+}
+
+}  // extern "C"
+
+// C++ forms of the reference's builder entry points (declared in host/scene_model.hpp).
+namespace dsrt {
+
+GPUScene build_gpu_scene(const hittable_list& world, const camera& cam, const vec3& sun_dir_model) {
+    GPUScene out;
+    std::memset(&out, 0, sizeof out);
+    DsrtHostScene* hs = dsrt_host_scene_create();
+    const float sun[3] = {sun_dir_model.x(), sun_dir_model.y(), sun_dir_model.z()};
+    const GPUCamera gc = cam.toGPUCamera();
+    if (flatten_world(world, hs) != DSRT_OK || dsrt_host_scene_build_bvh(hs) != DSRT_OK || dsrt_build_gpu_scene(hs, &gc, sun, &out) != DSRT_OK)
+        std::fprintf(stderr, "build_gpu_scene: %s\n", dsrt_last_error());
+    dsrt_host_scene_destroy(hs);
+    return out;
+}
+
+void free_gpu_scene(GPUScene& scene) { dsrt_free_gpu_scene(&scene); }
+
+}  // namespace dsrt

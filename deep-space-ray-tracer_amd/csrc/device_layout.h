@@ -1,0 +1,95 @@
+// device_layout.h -- how the scene lives in HBM, and the argument block of the render kernel.
+//
+// The reference keeps the scene as it came off the host: 116-byte AoS triangles, 40-byte AoS BVH nodes, an
+// index indirection between them (inc/gpu_scene.h:57-85), and tests three 24-byte boxes per internal node from
+// three different 40-byte records (src/gpu_render.cu:408-431).  Here the scene is re-laid-out ONCE at upload
+// for how a wave64 traversal actually touches it:
+//
+//   pairs      one 64-byte record per INTERNAL node holding BOTH children's boxes and both child references:
+//              a node visit is one aligned 64-byte gather per lane (4 x dwordx4), not three scattered ones.
+//                q0 = (L.lo.x, L.lo.y, L.lo.z, L.hi.x)   q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
+//                q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)   q3 = (left_ref, right_ref, -, -) as int bits
+//   child ref  >= 0: index of an internal node in `pairs`
+//              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles starting at slot
+//                    `payload` of the leaf-ordered triangle arrays; code 7: payload indexes `big_leaves` {first, count}
+//                    (leaves of more than 7 triangles only arise from coincident centroids, builder :408-414).
+//   tri_isect  triangles permuted into leaf order (slot j = tri_indices[j]; the indirection is gone), 48 bytes:
+//                (v0.x, v0.y, v0.z, e1.x) (e1.y, e1.z, e2.x, e2.y) (e2.z, 0, 0, 0),  e1 = v1 - v0, e2 = v2 - v0 in float,
+//              exactly the differences hit_triangle_index forms per test (src/gpu_render.cu:336-337).
+//   tri_shade  same order, 48 bytes, read once per closest hit, not per candidate:
+//                (n0.x, n0.y, n0.z, n1.x) (n1.y, n1.z, n2.x, n2.y) (n2.z, material_id, albedo_tex, original index)
+//   tri_uv     same order, 32 bytes, only allocated when the scene has textures: (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
+//   materials  the reference's 48-byte record viewed as 3 x float4.
+//   spheres / texture headers / texture pool: unchanged (few, wave-uniform or rarely touched).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dsrt_scene_abi.h"
+
+namespace dsrt {
+
+constexpr int kLeafBit = (int)0x80000000u;
+constexpr int kRefNone = 0x7FFFFFFF;           // "no node": traversal finished / no BVH
+
+__host__ __device__ inline bool ref_is_leaf(int r) { return r < 0; }
+__host__ __device__ inline int leaf_code(int r) { return (r >> 28) & 7; }
+__host__ __device__ inline int leaf_payload(int r) { return r & 0x0FFFFFFF; }
+inline int make_leaf_ref(int code, int payload) { return kLeafBit | (code << 28) | payload; }
+
+struct DeviceScene {
+    const float4* pairs;
+    const float4* tri_isect;
+    const float4* tri_shade;
+    const float4* tri_uv;
+    const int2*   big_leaves;
+    const float4* materials;
+    const GPUSphere* spheres;
+    const GPUTextureHeader* tex_headers;
+    const float*  tex_pool;
+    int   num_pairs, num_tris, num_big_leaves, num_materials;
+    int   num_spheres, num_lights, num_textures, tex_pool_floats;
+    float root_lo[3];
+    float root_hi[3];
+    int   root_ref;            // kRefNone when there is no BVH
+    int   stack_need;          // deepest the traversal stack can get for this BVH
+};
+
+struct FrameParams {
+    float cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3];
+    float sun_dir[3], sun_radiance[3];
+    int   sun_enabled;
+    int   width, height, spp, max_depth;
+    float inv_gamma;
+    uint32_t seed32;
+    int   tile;                // tile edge in pixels (multiple of 8)
+    int   tiles_x, tiles_y;
+    int   shard_rank, shard_count;
+    int   local_tiles;         // tiles owned by this shard
+    uint32_t total_items;      // local_tiles * tile * tile
+    int   compact_output;      // 1: tile-major shard buffer, 0: image order
+};
+
+struct RenderArgs {
+    DeviceScene scene;
+    FrameParams frame;
+    uint8_t*  out_rgb8;
+    float*    out_f32;
+    uint32_t* queue;           // [0] next work item
+    uint64_t* counters;        // kNumCounters entries (counting build only)
+    uint32_t* flags;           // checked-mode status word
+    uint2*    spill;           // stack overflow area: [(entry - K) * spill_stride + global lane]
+    uint32_t  spill_stride;
+    int       spill_entries;
+};
+
+// order matches the DsrtStats tail in include/dsrt.h
+enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
+               C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK, kNumCounters };
+
+// status bits raised by the checked build
+constexpr uint32_t kFlagBadNodeRef = 1u, kFlagBadTriSlot = 2u, kFlagBadMaterial = 4u, kFlagStackOverflow = 8u,
+                   kFlagStepCap = 16u, kFlagBadBigLeaf = 32u;
+
+}  // namespace dsrt

@@ -1,0 +1,41 @@
+// host_internal.hpp -- declarations shared by the host-side translation units (not installed).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "scene_model.hpp"
+
+namespace dsrt {
+
+void set_error(const std::string& msg);
+
+struct RgbImage {
+    int width = 0, height = 0;
+    std::vector<uint8_t> rgb;
+};
+bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img);
+
+bool texture_flip_latch();
+void texture_flip_latch_set(bool v);
+
+}  // namespace dsrt
+
+// The flattened scene: exactly the vectors build_gpu_scene uploads (src/gpu_scene_builder.cpp:183-190, 490-546).
+struct DsrtHostScene {
+    std::vector<GPUTriangle> tris;
+    std::vector<GPUSphere> spheres;
+    std::vector<GPUMaterial> mats;
+    std::vector<int> tri_indices;
+    std::vector<GPUBVHNode> nodes;
+    std::vector<GPUTextureHeader> tex_headers;
+    std::vector<float> tex_pool;
+
+    std::unordered_map<const dsrt::material*, int> mat_index;      // material object -> table slot
+    std::unordered_map<std::string, int> tex_index;                // texture path -> header slot
+    std::vector<std::shared_ptr<dsrt::material>> keep_alive;       // keeps mat_index keys unique for the scene's lifetime
+    bool bvh_valid = false;
+    int bvh_height = 0;                                            // levels; the traversal stack needs height - 1 entries
+};

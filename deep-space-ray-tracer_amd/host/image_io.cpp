@@ -1,0 +1,197 @@
+// image_io.cpp -- texture decode (PNM, PNG) to 8-bit RGB, and the P6 writer.
+//
+// The reference decodes textures with its vendored stb_image forced to 3 channels
+// (src/gpu_scene_builder.cpp:215) and writes frames as binary PPM (src/gpu_render.cu:1099-1107).
+// This file is an independent implementation of the two container formats we can support without
+// third-party code: binary/ASCII PNM and non-interlaced PNG (inflate through the system zlib).  Any other
+// format -- JPEG above all -- is reported as a load failure, for which the reference's own behaviour is a
+// 1x1 white texture plus a warning (src/gpu_scene_builder.cpp:216-221); the builder does the same.
+// Channel handling matches stb's req_comp = 3: gray is replicated, alpha is dropped, 16-bit keeps the
+// high byte, palette entries are expanded.
+#include "host_internal.hpp"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace dsrt {
+
+namespace {
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return false;
+    in.seekg(0, std::ios::end);
+    std::streamoff n = in.tellg();
+    if (n < 0) return false;
+    in.seekg(0, std::ios::beg);
+    out.resize((size_t)n);
+    if (n > 0) in.read((char*)out.data(), n);
+    return (bool)in || in.eof();
+}
+
+// ---------------- PNM ----------------
+struct Cursor {
+    const uint8_t* p;
+    const uint8_t* end;
+    void skip_space_and_comments() {
+        for (;;) {
+            while (p < end && std::isspace(*p)) ++p;
+            if (p < end && *p == '#') { while (p < end && *p != '\n') ++p; continue; }
+            break;
+        }
+    }
+    bool number(int& v) {
+        skip_space_and_comments();
+        if (p >= end || !std::isdigit(*p)) return false;
+        long acc = 0;
+        while (p < end && std::isdigit(*p)) { acc = acc * 10 + (*p - '0'); if (acc > (1 << 30)) return false; ++p; }
+        v = (int)acc;
+        return true;
+    }
+};
+
+bool decode_pnm(const std::vector<uint8_t>& f, RgbImage& img) {
+    if (f.size() < 3 || f[0] != 'P') return false;
+    const int kind = f[1] - '0';
+    if (kind != 2 && kind != 3 && kind != 5 && kind != 6) return false;
+    Cursor c{f.data() + 2, f.data() + f.size()};
+    int w, h, maxv;
+    if (!c.number(w) || !c.number(h) || !c.number(maxv)) return false;
+    if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) return false;
+    const int ch = (kind == 3 || kind == 6) ? 3 : 1;
+    const size_t count = (size_t)w * h * ch;
+    std::vector<uint8_t> raw(count);
+    if (kind == 5 || kind == 6) {
+        if (c.p < c.end) ++c.p;                       // the single whitespace after maxval
+        const size_t bps = maxv > 255 ? 2 : 1;
+        if ((size_t)(c.end - c.p) < count * bps) return false;
+        for (size_t i = 0; i < count; ++i) raw[i] = c.p[i * bps];   // 16-bit samples are big-endian: high byte first
+    } else {
+        for (size_t i = 0; i < count; ++i) {
+            int v;
+            if (!c.number(v)) return false;
+            raw[i] = (uint8_t)(maxv > 255 ? (v >> 8) : v);
+        }
+    }
+    img.width = w;
+    img.height = h;
+    img.rgb.resize((size_t)w * h * 3);
+    for (size_t px = 0; px < (size_t)w * h; ++px)
+        for (int k = 0; k < 3; ++k) img.rgb[px * 3 + k] = raw[px * ch + (ch == 3 ? k : 0)];
+    return true;
+}
+
+// ---------------- PNG ----------------
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (f.size() < 8 || std::memcmp(f.data(), sig, 8) != 0) return false;
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette;
+    bool seen_end = false;
+    while (pos + 12 <= f.size() && !seen_end) {
+        const uint32_t len = be32(&f[pos]);
+        const uint8_t* tag = &f[pos + 4];
+        if (pos + 12 + (size_t)len > f.size()) return false;
+        const uint8_t* body = &f[pos + 8];
+        if (!std::memcmp(tag, "IHDR", 4)) {
+            if (len < 13) return false;
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (!std::memcmp(tag, "PLTE", 4)) palette.assign(body, body + len);
+        else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(tag, "IEND", 4)) seen_end = true;
+        pos += 12 + (size_t)len;
+    }
+    if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || interlace != 0) return false;
+    int channels;
+    switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
+                     case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
+    const size_t bits_pp = (size_t)channels * depth;
+    const size_t stride = (w * bits_pp + 7) / 8;
+    const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
+
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    img.width = (int)w;
+    img.height = (int)h;
+    img.rgb.resize((size_t)w * h * 3);
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* line = &raw[(stride + 1) * y];
+        const int filter = line[0];
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = line[1 + i];
+            switch (filter) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+                              case 4: v += paeth(a, b, c); break; default: return false; }
+            cur[i] = (uint8_t)v;
+        }
+        for (uint32_t x = 0; x < w; ++x) {
+            uint8_t s[4] = {0, 0, 0, 0};
+            for (int k = 0; k < channels; ++k) {
+                if (depth >= 8) s[k] = cur[(x * channels + k) * (depth / 8)];
+                else {
+                    const size_t bit = (size_t)x * depth;
+                    const int v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+                    s[k] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+                }
+            }
+            uint8_t* o = &img.rgb[((size_t)y * w + x) * 3];
+            if (ctype == 3) {
+                const size_t e = (size_t)s[0] * 3;
+                if (e + 2 < palette.size()) { o[0] = palette[e]; o[1] = palette[e + 1]; o[2] = palette[e + 2]; }
+                else o[0] = o[1] = o[2] = 0;
+            } else if (channels <= 2) o[0] = o[1] = o[2] = s[0];
+            else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+
+}  // namespace
+
+bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img) {
+    std::vector<uint8_t> f;
+    if (!read_file(path, f)) return false;
+    if (!decode_png(f, img) && !decode_pnm(f, img)) return false;
+    if (flip_vertically) {
+        const size_t row = (size_t)img.width * 3;
+        std::vector<uint8_t> tmp(row);
+        for (int y = 0; y < img.height / 2; ++y) {
+            uint8_t* a = &img.rgb[(size_t)y * row];
+            uint8_t* b = &img.rgb[(size_t)(img.height - 1 - y) * row];
+            std::memcpy(tmp.data(), a, row); std::memcpy(a, b, row); std::memcpy(b, tmp.data(), row);
+        }
+    }
+    return true;
+}
+
+}  // namespace dsrt
+
+extern "C" int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, int height) {
+    if (!path || !rgb || width <= 0 || height <= 0) { dsrt::set_error("dsrt_write_ppm: bad argument"); return DSRT_ERR_INVALID; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { dsrt::set_error(std::string("cannot open ") + path + " for writing"); return DSRT_ERR_IO; }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    const size_t n = (size_t)width * height * 3;
+    const size_t done = std::fwrite(rgb, 1, n, f);
+    std::fclose(f);
+    if (done != n) { dsrt::set_error(std::string("short write to ") + path); return DSRT_ERR_IO; }
+    return DSRT_OK;
+}

@@ -1,0 +1,192 @@
+/*
+ * dsrt.h -- C ABI of libdsrt_hip.so, the MI355X-native renderer behind the Deep-Space-Ray-Tracer
+ * host API.  Plain C types only: pointers, sizes, PODs from dsrt_scene_abi.h.  No torch types, no
+ * C++ classes.  Every entry point names the reference interface it stands in for
+ * (file:line relative to the reference repository).
+ *
+ * Error model: every int-returning function returns DSRT_OK (0) or a negative DSRT_ERR_*; the text
+ * of the last failure on the calling thread is available from dsrt_last_error().  The reference
+ * prints to stderr and returns void (src/gpu_render.cu:1053-1094, src/gpu_scene_builder.cpp:27-34);
+ * the drop-in wrappers at the bottom keep that behaviour on top of these functions.
+ *
+ * Threading: a DsrtHostScene or DsrtContext may be used by one thread at a time.
+ */
+#ifndef DSRT_H
+#define DSRT_H
+
+#include "dsrt_scene_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSRT_OK               0
+#define DSRT_ERR_INVALID     -1   /* bad argument                                              */
+#define DSRT_ERR_IO          -2   /* file could not be read / written                          */
+#define DSRT_ERR_HIP         -3   /* a HIP runtime call failed                                 */
+#define DSRT_ERR_NO_DEVICE   -4   /* no usable gfx950 device                                   */
+#define DSRT_ERR_BVH_DEPTH   -5   /* BVH deeper than the 64-entry stack of src/gpu_render.cu:399 */
+#define DSRT_ERR_NO_SCENE    -6   /* render before upload                                      */
+#define DSRT_ERR_DEVICE_FLAG -7   /* the kernel raised its checked-mode status word            */
+
+const char* dsrt_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int dsrt_abi_version(void);
+
+/* ===================================================================================== */
+/* Host scene assembly -- no GPU involved.                                               */
+/* Replaces the flattening half of build_gpu_scene (src/gpu_scene_builder.cpp:464-601):  */
+/* collect_world :252-317, upsert_material :71-139, HostTextureRegistry :199-246,        */
+/* build_bvh_for_triangles :343-459, and the OBJ/MTL loader inc/triangle_mesh.h:75-255.  */
+/* ===================================================================================== */
+typedef struct DsrtHostScene DsrtHostScene;
+
+DsrtHostScene* dsrt_host_scene_create(void);
+void           dsrt_host_scene_destroy(DsrtHostScene* hs);
+
+/* Append the triangles of an OBJ file (with its MTL materials / map_Kd textures), exactly as
+ * `world.add(make_shared<triangle_mesh>(path, lambertian(0.73), scale))` followed by the builder's
+ * collect step would (src/main.cpp:238-245, src/gpu_scene_builder.cpp:259-283). */
+int dsrt_host_scene_add_obj(DsrtHostScene* hs, const char* obj_path, double scale);
+
+/* Append objects described in the small "world description" text format used by the tests and the
+ * CLI (mat / sphere / tri / obj lines).  Objects are flattened in file order. */
+int dsrt_host_scene_add_world_file(DsrtHostScene* hs, const char* world_path);
+
+/* Append already-flattened primitives (reference layouts).  Material ids are rebased onto the
+ * scene's material table. */
+int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int num_tris, const GPUSphere* spheres,
+                               int num_spheres, const GPUMaterial* mats, int num_mats);
+
+/* Median-split BVH over all triangles added so far: leaf <= 4, std::nth_element on the centroid along
+ * the widest centroid axis, pre-order node numbering (src/gpu_scene_builder.cpp:343-459). */
+int dsrt_host_scene_build_bvh(DsrtHostScene* hs);
+
+/* Fill `out` with HOST pointers into the scene's arrays (valid until the scene is modified or
+ * destroyed).  Camera / params / sun fields of `out` are zeroed; set them with dsrt_scene_set_frame. */
+int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out);
+
+/* Greatest number of entries the reference traversal's stack can hold for this BVH (= height - 1). */
+int dsrt_host_scene_bvh_stack_need(const DsrtHostScene* hs);
+
+/* Defaults of build_gpu_scene for everything that is not geometry (src/gpu_scene_builder.cpp:560-598):
+ * camera, params {gamma 2, exposure 50, use_bvh 1, rng_mode 0, tile_size 0}, black sky, seed 1337,
+ * sun enabled with radiance (1e5, 9.5e4, 9e4). */
+void dsrt_scene_set_frame(GPUScene* scene, const GPUCamera* cam, const float sun_dir_model[3]);
+
+/* ===================================================================================== */
+/* Pose file and camera -- src/main.cpp:139-173 (reader), :310-357 (world->model), :178-187 and
+ * inc/camera.h:91-133 (camera).                                                          */
+/* ===================================================================================== */
+typedef struct DsrtPose {
+    double cam_pos_world[3];
+    double model_pos_world[3];
+    float  model_euler_deg[3];      /* yaw, pitch, roll -- stored as float like PoseEntry, main.cpp:95-99 */
+} DsrtPose;
+
+typedef struct DsrtFrame {
+    float  cam_in_model[3];
+    float  sun_dir_model[3];
+    double sep_m;
+    int    skipped;                 /* sep_m < 1.0: the reference skips the frame, main.cpp:342-345 */
+} DsrtFrame;
+
+/* Reads up to `cap` poses; *count receives the number of valid lines in the file (may exceed cap).
+ * Returns DSRT_ERR_IO if the file cannot be opened or holds no valid pose (read_pose_file returns false). */
+int dsrt_read_pose_file(const char* path, DsrtPose* out, int cap, int* count);
+int dsrt_pose_to_frame(const DsrtPose* pose, DsrtFrame* out);
+/* point_camera_at + camera::initialize + toGPUCamera: vup (0,1,0), aperture 0, focus = |from - at|. */
+int dsrt_camera_look_at(GPUCamera* out, const float from[3], const float at[3], float vfov_deg, int width, int height,
+                        int spp, int max_depth);
+
+/* P6 writer, as the tail of gpu_render_scene (src/gpu_render.cu:1099-1107). */
+int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, int height);
+
+/* ===================================================================================== */
+/* Device side.                                                                          */
+/* ===================================================================================== */
+typedef struct DsrtContext DsrtContext;
+
+int  dsrt_device_count(void);
+int  dsrt_ctx_create(int device, DsrtContext** out);
+void dsrt_ctx_destroy(DsrtContext* ctx);
+
+/* Upload + re-layout for the GPU (once per scene, not per frame).  `scene` holds HOST pointers in the
+ * reference layouts (as from dsrt_host_scene_view); its camera/params/sun are recorded as the current frame.
+ * Replaces the upload half of build_gpu_scene (src/gpu_scene_builder.cpp:322-331, 475-546). */
+int dsrt_scene_upload(DsrtContext* ctx, const GPUScene* scene);
+/* Same, for a GPUScene whose array members are DEVICE pointers (what the reference's own builder
+ * produces and what gpu_render_scene receives, src/gpu_render.cu:1037-1066). */
+int dsrt_scene_upload_device(DsrtContext* ctx, const GPUScene* scene);
+/* Per-frame update: only camera and sun change between frames (src/main.cpp:399-405). */
+int dsrt_scene_set_camera_sun(DsrtContext* ctx, const GPUCamera* cam, const float sun_dir_model[3]);
+
+typedef struct DsrtRenderDesc {
+    int      width, height;         /* gpu_render_scene(scene, width, height)                     */
+    int      spp;                   /* <1 -> 1, as src/gpu_render.cu:987-988                      */
+    int      max_depth;             /* <=0 -> 12, as :723-725                                     */
+    float    gamma;                 /* <=0 -> 1, as :1043                                         */
+    uint64_t seed;
+    int      rng_mode;              /* 0 = reference LCG stream per pixel (parity mode)           */
+    int      tile_size;             /* screen-tile edge in pixels, multiple of 8; 0 -> 8          */
+    int      shard_rank;            /* this process renders tiles t with t % shard_count == shard_rank */
+    int      shard_count;           /* 0 or 1 -> whole image                                      */
+    int      collect_counters;      /* 1 -> run the counting build of the kernel, fill DsrtStats counters */
+    int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
+    int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
+    int      reserved[3];
+} DsrtRenderDesc;
+
+typedef struct DsrtStats {
+    float    kernel_ms;             /* HIP events around the render kernel on the given stream (0 if timing off) */
+    int      waves_launched;
+    uint32_t device_flags;          /* checked-mode status word (0 = clean)                       */
+    int      lds_stack_entries;
+    uint64_t samples, rays, primary_hits, box_fetches, nodes_entered, internal_entered, tri_tests, hit_updates,
+             sphere_tests, shaded_hits, tex_fetches, stack_spills, max_stack;
+} DsrtStats;
+
+/* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of
+ * tiles this shard owns / the padded per-shard tile count (equal on every rank, for a gather). */
+int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_this_shard, int* tiles_per_shard_padded,
+                      size_t* rgb8_bytes_padded);
+
+/*
+ * Render.  Asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream) unless
+ * `stats` is non-NULL, in which case the call synchronises the stream and fills `stats`.
+ *   d_rgb8 : DEVICE buffer.  shard_count <= 1: width*height*3 bytes in image order (top row first), what
+ *            the reference copies back and writes after the P6 header (src/gpu_render.cu:1087-1106).
+ *            shard_count  > 1: tiles_per_shard_padded * tile*tile*3 bytes, tile-major, local tile k =
+ *            global tile k*shard_count + shard_rank, rows of a tile top first.
+ *   d_f32  : optional DEVICE buffer, same indexing, 3 floats per pixel: the value multiplied by 255.99
+ *            (:1028), for the L-infinity parity check.  May be NULL.
+ */
+int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats);
+
+/* Root rank, after a gather: tile-major shards [shard][tile][tile*tile*3] -> image-order rgb8. */
+int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image,
+                            void* stream);
+
+/* Convenience for hosts without their own device buffers: render the whole image into HOST memory. */
+int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h_rgb8, float* h_f32, DsrtStats* stats);
+
+/* Device evaluation of the shared deterministic math (tests): out[i] = f(x[i]) on the GPU;
+ * fn 0 = sin, 1 = cos, 2 = pow(x[i], y).  Host pointers. */
+int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n);
+
+/* ===================================================================================== */
+/* Drop-in layer: the reference's own three entry points.                                */
+/* ===================================================================================== */
+/* src/gpu_render.cu:1037-1038, declared at its call site src/main.cpp:24-25.  `scene` holds DEVICE pointers.
+ * Blocking; writes image_gpu.ppm into the CWD; failures print to stderr and return (no file). */
+void gpu_render_scene(const GPUScene* scene, int width, int height);
+
+/* C forms of build_gpu_scene / free_gpu_scene (inc/gpu_scene_builder.h:72-73): the C++ overloads taking
+ * hittable_list/camera/vec3 live in deep-space-ray-tracer_amd/host/scene_model.hpp and forward here. */
+int  dsrt_build_gpu_scene(const DsrtHostScene* hs, const GPUCamera* cam, const float sun_dir_model[3], GPUScene* out);
+void dsrt_free_gpu_scene(GPUScene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSRT_H */

@@ -1,0 +1,82 @@
+/*
+ * dsrt_oracle.h -- CPU restatement of the reference's per-pixel x spp sampling loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (include/, deep-space-ray-tracer_amd/) may
+ * include, link or call this.  Allowed users: tests/, __graft_entry__.smoke(), and the
+ * `cpu_baseline` leg of bench.py -- always as the checker / the reported CPU baseline, never as
+ * the thing measured or shipped.
+ *
+ * What it restates: src/gpu_render.cu of the reference (render_kernel :973-1031 and everything
+ * it calls; each function in dsrt_oracle.c cites its lines).  Arithmetic is fp32, same operation
+ * order, compiled with -ffp-contract=off.
+ *
+ * Pinning status (read before trusting it):
+ *   - The reference has no tests, golden images or known-answer vectors, and its
+ *     render kernel is a CUDA translation unit that cannot be built in this image (no nvcc, no
+ *     libcudart; we do not write stand-ins).  The sampling loop restated here is therefore
+ *     **parity unpinned** against an execution of the reference: it is a line-by-line
+ *     restatement checked by review, by the LCG / pose known answers SURVEY.md section 8 records, and
+ *     by cross-checks against the reference's own CPU classes (sphere::hit, triangle::hit,
+ *     aabb::hit) where those compute the same quantity.
+ *   - Everything that FEEDS the loop (pose -> camera, OBJ/MTL -> triangles/materials, flattening,
+ *     median-split BVH) is pinned against the reference's real host code compiled from
+ *     /root/reference by oracle/Makefile into oracle/_ref/ (goldens in tests/golden/).
+ *   - cosf/sinf/powf come from include/dsrt_detmath.h (shared with the HIP kernel), not from any
+ *     libm: see that header.  Build with -DDSRT_ORACLE_LIBM to use the host libm instead (for the
+ *     statistical comparison only).
+ */
+#ifndef DSRT_ORACLE_H
+#define DSRT_ORACLE_H
+
+#include "../include/dsrt_scene_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Work counters, all per call (added to, not reset).  Definitions follow SURVEY.md section 8(d). */
+typedef struct DsrtOracleCounters {
+    uint64_t samples;          /* ray_color invocations                                         */
+    uint64_t rays;             /* scene_hit invocations (primary + bounce + shadow)             */
+    uint64_t primary_hits;     /* samples whose depth-0 ray hit something                       */
+    uint64_t box_tests;        /* every bbox_hit call the reference makes (incl. its re-tests)  */
+    uint64_t box_fetches;      /* n_box: distinct node boxes read = 1 per BVH ray + 2 per internal node entered */
+    uint64_t nodes_entered;    /* n_enter: nodes whose own bbox test passed                     */
+    uint64_t internal_entered; /* of those, internal nodes                                      */
+    uint64_t tri_tests;        /* n_tri: Moller-Trumbore evaluations                            */
+    uint64_t hit_updates;      /* n_upd: accepted closest-hit updates                           */
+    uint64_t sphere_tests;
+    uint64_t shaded_hits;      /* material fetches                                              */
+    uint64_t tex_fetches;
+    uint64_t max_stack;        /* max BVH stack depth seen                                      */
+    uint64_t rng_draws;
+} DsrtOracleCounters;
+
+/*
+ * Render rows [y0, y1) (kernel coordinates: y = 0 is the BOTTOM row of the image, exactly as
+ * blockIdx.y*8+threadIdx.y in src/gpu_render.cu:984; the store flips to row H-1-y, :1027).
+ * `scene` is a GPUScene whose array members are HOST pointers.
+ *   rgb8    : W*H*3 bytes, image order (top row first), or NULL
+ *   rgb_f32 : W*H*3 floats, same indexing, the value that is multiplied by 255.99 (:1028), or NULL
+ * Returns 0, or a negative number for invalid arguments.
+ */
+int dsrt_oracle_render_rows(const GPUScene* scene, int W, int H, int y0, int y1,
+                            uint8_t* rgb8, float* rgb_f32, DsrtOracleCounters* counters);
+
+/* rand01 of src/gpu_render.cu:77-80, exposed for the known-answer test. */
+float dsrt_oracle_rand01(uint32_t* state);
+
+/* One scene_hit (src/gpu_render.cu:509-551) for ray-level tests.  out = {t, px,py,pz, nx,ny,nz, u, v};
+ * ids = {mat_id, tri_tex_id, tri_index, front_face}.  Returns 1 on hit. */
+int dsrt_oracle_scene_hit(const GPUScene* scene, const float orig[3], const float dir[3],
+                          float t_min, float t_max, float out[9], int ids[4]);
+
+/* The shared deterministic math, exposed so tests can compare device results bit for bit. */
+float dsrt_oracle_sinf(float x);
+float dsrt_oracle_cosf(float x);
+float dsrt_oracle_powf(float x, float y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

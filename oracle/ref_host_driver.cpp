@@ -1,0 +1,248 @@
+// ref_host_driver.cpp -- drives the REFERENCE'S OWN host code to produce golden vectors.
+//
+// TEST INFRASTRUCTURE ONLY (see dsrt_oracle.h).  This file is ours; everything it calls is the
+// reference's, compiled from the sources where they lie (the three #includes below).  Nothing from
+// the reference is copied into this repository: the only things committed are the OUTPUTS
+// (tests/golden/*, made by tests/golden/make_golden.py running the binary built from this file).
+//
+// Reference code exercised (file:line in /root/reference):
+//   src/main.cpp               read_pose_file :139-173, rotate_yaw_deg_d :118-128, dnormalize :78-82,
+//                              to_float_vec3 :84-86, point_camera_at :178-187 (static functions; `main`
+//                              itself is renamed away and garbage-collected at link time)
+//   inc/camera.h               camera::initialize :91-116, toGPUCamera :118-133
+//   inc/triangle_mesh.h        OBJ / MTL loader :75-255
+//   src/gpu_scene_builder.cpp  collect_world :310-317, upsert_material :71-139, HostTextureRegistry :199-246,
+//                              build_bvh_for_triangles :444-459  (build_gpu_scene / free_gpu_scene, the
+//                              only functions needing libcudart, are never referenced and are dropped by
+//                              --gc-sections)
+//   inc/aabb.h, sphere.h, triangle.h, hittable_list.h    the CPU hit classes, for ray-level cross-checks
+//
+// NOT exercised, because it cannot be built here: src/gpu_render.cu (the CUDA kernel).
+
+#define main dsrt_unused_reference_main
+#include "src/main.cpp"
+#undef main
+#include "src/gpu_scene_builder.cpp"
+#include "src/stb_image_impl.cpp"
+
+#include <cinttypes>
+#include <cstring>
+#include <map>
+
+static void hex_bytes(const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) std::printf("%02x", b[i]);
+}
+static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+template <typename T>
+static void dump_vec(const std::string& path, const std::vector<T>& v) {
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { std::fprintf(stderr, "cannot write %s\n", path.c_str()); std::exit(2); }
+    if (!v.empty()) std::fwrite(v.data(), sizeof(T), v.size(), f);
+    std::fclose(f);
+}
+
+// ---- "world description" text format (ours): one object per line, in insertion order -------------
+//   mat <name> lambertian r g b | metal r g b fuzz | dielectric ior | light r g b
+//   sphere cx cy cz radius <mat>
+//   tri x0 y0 z0 x1 y1 z1 x2 y2 z2 <mat>
+//   obj <path> [scale]            (fallback material lambertian(0.73), src/main.cpp:240)
+static hittable_list load_world(const std::string& path) {
+    hittable_list world;
+    std::map<std::string, std::shared_ptr<material>> mats;
+    std::ifstream in(path);
+    if (!in) { std::fprintf(stderr, "cannot read %s\n", path.c_str()); std::exit(2); }
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream iss(line);
+        std::string tag; iss >> tag;
+        if (tag == "mat") {
+            std::string name, kind; iss >> name >> kind;
+            double a, b, c, d;
+            if (kind == "lambertian") { iss >> a >> b >> c; mats[name] = std::make_shared<lambertian>(color(a, b, c)); }
+            else if (kind == "metal") { iss >> a >> b >> c >> d; mats[name] = std::make_shared<metal>(color(a, b, c), d); }
+            else if (kind == "dielectric") { iss >> a; mats[name] = std::make_shared<dielectric>(a); }
+            else if (kind == "light") { iss >> a >> b >> c; mats[name] = std::make_shared<diffuse_light>(color(a, b, c)); }
+        } else if (tag == "sphere") {
+            double x, y, z, r; std::string m; iss >> x >> y >> z >> r >> m;
+            world.add(std::make_shared<sphere>(point3(x, y, z), r, mats.at(m)));
+        } else if (tag == "tri") {
+            double v[9]; for (double& q : v) iss >> q; std::string m; iss >> m;
+            world.add(std::make_shared<triangle>(vec3(v[0], v[1], v[2]), vec3(v[3], v[4], v[5]), vec3(v[6], v[7], v[8]), mats.at(m)));
+        } else if (tag == "obj") {
+            std::string p; double scale = 1.0; iss >> p; iss >> scale;
+            auto fallbackM = std::make_shared<lambertian>(vec3(0.73, 0.73, 0.73));
+            world.add(std::make_shared<triangle_mesh>(p, fallbackM, scale));
+        }
+    }
+    return world;
+}
+
+static int cmd_scene(const std::string& world_path, const std::string& prefix) {
+    hittable_list world = load_world(world_path);
+    HostBuild B;
+    HostTextureRegistry texreg;
+    collect_world(world, B, texreg);
+    std::vector<int> idx;
+    std::vector<GPUBVHNode> nodes;
+    build_bvh_for_triangles(B.h_tris, idx, nodes);
+
+    std::vector<GPUTextureHeader> headers;
+    std::vector<float> pool;
+    int off = 0;
+    for (const auto& ht : texreg.textures) {              // as src/gpu_scene_builder.cpp:513-535
+        GPUTextureHeader h{}; h.width = ht.width; h.height = ht.height; h.offset = off;
+        headers.push_back(h);
+        pool.insert(pool.end(), ht.data.begin(), ht.data.end());
+        off += (int)ht.data.size();
+    }
+    dump_vec(prefix + ".tris.bin", B.h_tris);
+    dump_vec(prefix + ".spheres.bin", B.h_spheres);
+    dump_vec(prefix + ".mats.bin", B.h_mats);
+    dump_vec(prefix + ".idx.bin", idx);
+    dump_vec(prefix + ".nodes.bin", nodes);
+    dump_vec(prefix + ".texhdr.bin", headers);
+    dump_vec(prefix + ".texpool.bin", pool);
+    std::printf("{\"num_triangles\": %zu, \"num_spheres\": %zu, \"num_materials\": %zu, \"num_bvh_nodes\": %zu, "
+                "\"num_textures\": %zu, \"texture_pool_floats\": %zu}\n",
+                B.h_tris.size(), B.h_spheres.size(), B.h_mats.size(), nodes.size(), headers.size(), pool.size());
+    return 0;
+}
+
+static void print_camera_json(const camera& cam) {
+    GPUCamera g = cam.toGPUCamera();
+    std::printf("\"gpu_camera\": \"");
+    hex_bytes(&g, sizeof g);
+    std::printf("\"");
+}
+
+static int cmd_camera(int argc, char** argv) {
+    if (argc < 13) return 2;
+    camera cam;
+    cam.image_width = std::atoi(argv[9]);
+    cam.image_height = std::atoi(argv[10]);
+    cam.samples_per_pixel = std::atoi(argv[11]);
+    cam.max_depth = std::atoi(argv[12]);
+    cam.vfov = (float)std::atof(argv[8]);
+    cam.aperture = 0.0;
+    vec3 from((float)std::atof(argv[2]), (float)std::atof(argv[3]), (float)std::atof(argv[4]));
+    vec3 at((float)std::atof(argv[5]), (float)std::atof(argv[6]), (float)std::atof(argv[7]));
+    point_camera_at(cam, from, at);                        // src/main.cpp:178-187
+    std::printf("{");
+    print_camera_json(cam);
+    std::printf("}\n");
+    return 0;
+}
+
+// The per-frame arithmetic of src/main.cpp:310-399, restated as CALLS to the reference's own functions.
+static int cmd_poses(int argc, char** argv) {
+    if (argc < 8) return 2;
+    std::vector<PoseEntry> poses;
+    if (!read_pose_file(argv[2], poses)) { std::printf("{\"error\": \"no poses\"}\n"); return 1; }
+    camera cam;
+    cam.image_width = std::atoi(argv[3]);
+    cam.image_height = std::atoi(argv[4]);
+    cam.samples_per_pixel = std::atoi(argv[5]);
+    cam.max_depth = std::atoi(argv[6]);
+    cam.vfov = (float)std::atof(argv[7]);
+    cam.aperture = 0.0;
+    dvec3 light_pos_world_d(0.0, 0.0, 0.0);
+    std::printf("[\n");
+    for (size_t i = 0; i < poses.size(); ++i) {
+        const PoseEntry& p = poses[i];
+        double yaw_deg = p.model_euler_deg.x();
+        dvec3 cam_rel_world_d = p.cam_pos_world_d - p.model_pos_world_d;
+        dvec3 light_rel_world_d = light_pos_world_d - p.model_pos_world_d;
+        double sep_m = dlength(cam_rel_world_d);
+        bool skipped = sep_m < 1.0;
+        dvec3 cam_in_model_d = rotate_yaw_deg_d(cam_rel_world_d, -yaw_deg);
+        dvec3 light_in_model_d = rotate_yaw_deg_d(light_rel_world_d, -yaw_deg);
+        vec3 cam_in_model = to_float_vec3(cam_in_model_d);
+        dvec3 sun_dir_model_d = dnormalize(light_in_model_d);
+        vec3 sun_dir_model = to_float_vec3(sun_dir_model_d);
+        std::printf("{\"frame\": %zu, \"skipped\": %s, \"sep_m\": %.17g, "
+                    "\"cam_in_model\": [%" PRIu32 ", %" PRIu32 ", %" PRIu32 "], "
+                    "\"sun_dir_model\": [%" PRIu32 ", %" PRIu32 ", %" PRIu32 "], ",
+                    i, skipped ? "true" : "false", sep_m,
+                    fbits(cam_in_model.x()), fbits(cam_in_model.y()), fbits(cam_in_model.z()),
+                    fbits(sun_dir_model.x()), fbits(sun_dir_model.y()), fbits(sun_dir_model.z()));
+        if (!skipped) point_camera_at(cam, cam_in_model, vec3(0, 0, 0));
+        print_camera_json(cam);
+        std::printf("}%s\n", i + 1 < poses.size() ? "," : "");
+    }
+    std::printf("]\n");
+    return 0;
+}
+
+static int cmd_abi() {
+#define SZ(T) std::printf("\"sizeof_" #T "\": %zu, ", sizeof(T))
+#define OFF(T, m) std::printf("\"" #T "." #m "\": %zu, ", offsetof(T, m))
+    std::printf("{");
+    SZ(GPUTextureHeader); SZ(GPUMaterial); SZ(GPUSphere); SZ(GPUTriangle); SZ(GPUBVHNode);
+    SZ(GPURenderParams); SZ(GPUCamera); SZ(GPUScene);
+    OFF(GPUMaterial, albedo); OFF(GPUMaterial, emissive); OFF(GPUMaterial, fuzz); OFF(GPUMaterial, ref_idx);
+    OFF(GPUSphere, radius); OFF(GPUSphere, material_id);
+    OFF(GPUTriangle, v0); OFF(GPUTriangle, n0); OFF(GPUTriangle, uv0); OFF(GPUTriangle, material_id); OFF(GPUTriangle, albedo_tex);
+    OFF(GPUBVHNode, bbox_min); OFF(GPUBVHNode, bbox_max); OFF(GPUBVHNode, left); OFF(GPUBVHNode, right);
+    OFF(GPUBVHNode, tri_offset); OFF(GPUBVHNode, tri_count);
+    OFF(GPURenderParams, samples_per_pixel); OFF(GPURenderParams, max_depth); OFF(GPURenderParams, rng_mode);
+    OFF(GPURenderParams, tile_size); OFF(GPURenderParams, gamma); OFF(GPURenderParams, exposure);
+    OFF(GPUCamera, origin); OFF(GPUCamera, lower_left_corner); OFF(GPUCamera, horizontal); OFF(GPUCamera, vertical);
+    OFF(GPUCamera, u); OFF(GPUCamera, lens_radius); OFF(GPUCamera, image_width); OFF(GPUCamera, max_depth);
+    OFF(GPUScene, spheres); OFF(GPUScene, num_spheres); OFF(GPUScene, triangles); OFF(GPUScene, tri_indices);
+    OFF(GPUScene, num_triangles); OFF(GPUScene, bvh_nodes); OFF(GPUScene, num_bvh_nodes); OFF(GPUScene, bvh_tri_indices);
+    OFF(GPUScene, materials); OFF(GPUScene, num_materials); OFF(GPUScene, textures); OFF(GPUScene, num_textures);
+    OFF(GPUScene, texture_pool); OFF(GPUScene, texture_pool_floats); OFF(GPUScene, camera); OFF(GPUScene, sky_type);
+    OFF(GPUScene, env_tex_id); OFF(GPUScene, sky_solid); OFF(GPUScene, sky_top); OFF(GPUScene, sky_bottom);
+    OFF(GPUScene, params); OFF(GPUScene, seed); OFF(GPUScene, sun_enabled); OFF(GPUScene, sun_dir); OFF(GPUScene, sun_radiance);
+    std::printf("\"end\": 0}\n");
+    return 0;
+}
+
+// Ray-level known answers from the reference's CPU classes.  Rays come from the same 32-bit LCG the
+// kernel uses (so the test can regenerate them); values are printed as float/double bit patterns.
+static float lcg01(uint32_t& s) { s = s * 1664525u + 1013904223u; return (s & 0x00FFFFFFu) / 16777216.0f; }
+static int cmd_hitkat(int n) {
+    uint32_t s = 2024u;
+    auto m = std::make_shared<lambertian>(color(0.5, 0.5, 0.5));
+    sphere sph(point3(0.25f, -0.125f, -1.0f), 0.5, m);
+    triangle tri(vec3(-1.0f, -0.5f, -2.0f), vec3(1.5f, -0.25f, -2.5f), vec3(0.0f, 1.25f, -1.5f), m);
+    aabb box(point3(-0.5f, -0.25f, -1.75f), point3(0.75f, 0.5f, -1.0f));
+    std::printf("[\n");
+    for (int i = 0; i < n; ++i) {
+        vec3 o(lcg01(s) - 0.5f, lcg01(s) - 0.5f, lcg01(s) * 0.5f);
+        vec3 d(lcg01(s) * 2.0f - 1.0f, lcg01(s) * 2.0f - 1.0f, -(lcg01(s) + 0.25f));
+        if (i % 7 == 3) d = vec3(0.0f, d.y(), d.z());     // axis-parallel component: the 1/0 slab path
+        ray r(o, d);
+        hit_record rs, rt;
+        bool hs = sph.hit(r, interval(0.001, 1e9), rs);
+        bool ht = tri.hit(r, interval(0.001, 1e9), rt);
+        bool hb = box.hit(r, interval(0.001, 1e9));
+        uint64_t ts = 0, tt = 0;
+        if (hs) std::memcpy(&ts, &rs.t, 8);
+        if (ht) std::memcpy(&tt, &rt.t, 8);
+        std::printf("{\"o\": [%u, %u, %u], \"d\": [%u, %u, %u], \"sphere\": %d, \"sphere_t\": %" PRIu64
+                    ", \"tri\": %d, \"tri_t\": %" PRIu64 ", \"box\": %d}%s\n",
+                    fbits(o.x()), fbits(o.y()), fbits(o.z()), fbits(d.x()), fbits(d.y()), fbits(d.z()),
+                    hs ? 1 : 0, ts, ht ? 1 : 0, tt, hb ? 1 : 0, i + 1 < n ? "," : "");
+    }
+    std::printf("]\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: ref_host abi | scene <world.txt> <prefix> | camera fx fy fz ax ay az vfov W H spp depth |"
+                             " poses <pose.txt> W H spp depth vfov | hitkat <n>\n");
+        return 2;
+    }
+    std::string c = argv[1];
+    if (c == "abi") return cmd_abi();
+    if (c == "scene" && argc >= 4) return cmd_scene(argv[2], argv[3]);
+    if (c == "camera") return cmd_camera(argc, argv);
+    if (c == "poses") return cmd_poses(argc, argv);
+    if (c == "hitkat" && argc >= 3) return cmd_hitkat(std::atoi(argv[2]));
+    return 2;
+}

@@ -1,0 +1,116 @@
+"""Host side vs the REFERENCE'S OWN host code (vectors made by tests/golden/make_golden.py from oracle/_ref).
+
+Everything here is bit-exact: ABI offsets, pose -> frame, camera basis, OBJ/MTL flattening, texture pool, BVH.
+"""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, GOLDEN, load_world
+
+
+def _bits(f):
+    return struct.unpack("<I", struct.pack("<f", f))[0]
+
+
+def test_abi_matches_reference_layout(dsrt):
+    ref = json.load(open(os.path.join(GOLDEN, "ref_abi.json")))
+    capi = dsrt.capi
+    for key, want in ref.items():
+        if key == "end":
+            continue
+        if key.startswith("sizeof_"):
+            assert C.sizeof(getattr(capi, key[len("sizeof_"):])) == want, key
+        else:
+            struct_name, field = key.split(".")
+            assert getattr(getattr(capi, struct_name), field).offset == want, key
+
+
+def test_library_exports_every_declared_symbol(dsrt):
+    for name in dsrt.capi.EXPORTS:
+        assert hasattr(dsrt.lib, name), name
+    # and the header declares nothing we forgot to list
+    header = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "dsrt.h")).read()
+    import re
+    declared = set(re.findall(r"\b(dsrt_[a-z0-9_]+|gpu_render_scene)\s*\(", header))
+    assert declared == set(dsrt.capi.EXPORTS)
+    assert dsrt.lib.dsrt_abi_version() == 1
+
+
+def test_pose_file_and_world_to_model_transform(dsrt):
+    ref = json.load(open(os.path.join(GOLDEN, "ref_poses_640x360.json")))
+    poses = dsrt.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
+    assert len(poses) == len(ref) == 99          # 1 header + 99 pose lines
+    for i, (p, want) in enumerate(zip(poses, ref)):
+        f = dsrt.pose_to_frame(p)
+        assert [_bits(v) for v in f.cam_in_model] == want["cam_in_model"], i
+        assert [_bits(v) for v in f.sun_dir_model] == want["sun_dir_model"], i
+        assert f.sep_m == want["sep_m"] and bool(f.skipped) == want["skipped"], i
+        cam = dsrt.frame_camera(f, 40.0, 640, 360, 64, 50)
+        assert bytes(cam).hex() == want["gpu_camera"], i
+    # the two known answers SURVEY.md section 8(d) quotes
+    f0, f98 = dsrt.pose_to_frame(poses[0]), dsrt.pose_to_frame(poses[98])
+    assert np.allclose(list(f0.cam_in_model), [-0.72611237, 0.0, 1786.9741], rtol=0, atol=1e-4)
+    assert np.allclose(list(f0.sun_dir_model), [0.32780463, -0.7564221, 0.5660121], rtol=0, atol=1e-7)
+    assert np.allclose(list(f98.cam_in_model), [-0.000289917, 0.0, 35.739487], rtol=0, atol=1e-5)
+
+
+def test_pose_reader_skips_malformed_lines(dsrt, tmp_path):
+    p = tmp_path / "poses.txt"
+    p.write_text("# header\n\n1 2 3 4 5 6 7 8 9\nnot a pose\n1 2 3 4 5 6 7 8\n10 20 30 40 50 60 70 80 90 extra\n")
+    poses = dsrt.read_pose_file(p)
+    assert len(poses) == 2 and list(poses[1].cam_pos_world) == [10.0, 20.0, 30.0]
+    empty = tmp_path / "none.txt"
+    empty.write_text("# nothing\n")
+    with pytest.raises(dsrt.DsrtError):
+        dsrt.read_pose_file(empty)
+    with pytest.raises(dsrt.DsrtError):
+        dsrt.read_pose_file(tmp_path / "missing.txt")
+
+
+def test_camera_basis(dsrt):
+    for case in json.load(open(os.path.join(GOLDEN, "ref_cameras.json"))):
+        a = case["args"]
+        cam = dsrt.camera_look_at(a[0:3], a[3:6], a[6], a[7], a[8], a[9], a[10])
+        assert bytes(cam).hex() == case["gpu_camera"], a
+
+
+@pytest.mark.parametrize("name", ["c1_spheres", "lights", "station_3k", "textured", "quirks", "mixed"])
+def test_flatten_and_bvh_match_reference_builder(dsrt, name):
+    ref = np.load(os.path.join(GOLDEN, f"ref_scene_{name}.npz"))
+    counts = json.load(open(os.path.join(GOLDEN, "ref_scenes.json")))[name]["counts"]
+    got = load_world(dsrt, name).arrays()
+    assert len(got["tris"]) == counts["num_triangles"] and len(got["nodes"]) == counts["num_bvh_nodes"]
+    assert len(got["mats"]) == counts["num_materials"] and len(got["spheres"]) == counts["num_spheres"]
+    for key in ("tris", "spheres", "mats", "idx", "nodes", "texhdr", "texpool"):
+        assert got[key].tobytes() == ref[key].tobytes(), f"{name}: {key} differs from the reference builder"
+
+
+def test_big_leaf_and_stack_need(dsrt):
+    hs = load_world(dsrt, "quirks")
+    nodes = hs.arrays()["nodes"]
+    assert nodes["tri_count"].max() == 9          # nine coincident triangles cannot be split: one leaf of 9
+    assert hs.stack_need >= 1
+    hs3k = load_world(dsrt, "station_3k")
+    assert 8 <= hs3k.stack_need <= 16
+
+
+def test_loader_skips_out_of_range_indices(dsrt, tmp_path):
+    # the reference indexes past its vertex array here (undefined behaviour); we skip the offending triangle/face
+    obj = tmp_path / "bad.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\nf 1 2 9\nf 7 1 2\nf -1 1 2\nf 1 2 3 9\n")
+    hs = dsrt.HostScene().add_obj(obj)
+    assert len(hs.arrays()["tris"]) == 2
+    with pytest.raises(dsrt.DsrtError):
+        dsrt.HostScene().add_obj(tmp_path / "missing.obj")
+
+
+def test_ppm_writer(dsrt, tmp_path):
+    rgb = (np.arange(4 * 3 * 3) % 251).astype(np.uint8).reshape(3, 4, 3)
+    out = tmp_path / "o.ppm"
+    dsrt.write_ppm(out, rgb, 4, 3)
+    assert out.read_bytes() == b"P6\n4 3\n255\n" + rgb.tobytes()
