@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the per-pixel x spp sampling loop on the ISS-mesh frame BASELINE.json quotes
+(1920x1080 @ 1000 spp, max_depth 50), on 1..N MI355X of one node.
+
+A "step" is one complete render of the frame: every pixel, every sample, scene already resident in HBM in traversal layout
+(upload, BVH build and OBJ parsing are outside the timed region, as BASELINE.md section 3 prescribes; the reference redoes them per
+frame).  For N > 1 the image is sharded by interleaved 8x8 screen tiles (tile t -> rank t mod N), each rank renders its tiles
+into a compact buffer, one RCCL gather brings them to rank 0 and a small kernel restores image order -- all inside the step.
+
+Mesh: the real ISS OBJ is not available, so unless --obj is given the procedural stand-in from
+deep-space-ray-tracer_amd/meshgen.py is generated (--tris, default 1,000,000 triangles).  Pose: --frame of the reference's
+rendezvous_1s_dt0_01s.txt (tests/golden/ copy).  The default frame is 98 (camera 35.7 m from the station, which fills the
+view); frame 0 (1787 m, ~0.3 % of the pixels see the station) is an RNG + ray-generation benchmark and is reported
+separately with --also-far.  Every figure carries the mesh, the frame and the primary-ray coverage.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1, `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(st, pixels):
+    """B = 24*n_box + 16*n_enter + 40*n_tri + 44*n_upd + 48*shaded + 24*sphere tests + 3*pixels,
+    with the counters of the kernel that was actually run (any-hit shadow rays included)."""
+    return (24 * st.box_fetches + 16 * st.nodes_entered + 40 * st.tri_tests + 44 * st.hit_updates + 48 * st.shaded_hits +
+            24 * st.sphere_tests + 12 * st.tex_fetches + 3 * pixels)
+
+
+def cpu_baseline(d, scene, W, H, spp, budget_s):
+    """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: a band of rows around the
+    image centre at full spp, split over all host cores (each row range is independent)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    orc = Oracle()
+    cores = os.cpu_count() or 1
+
+    def run(y0, y1, threads):
+        cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in range(threads)]
+        per = (y1 - y0 + threads - 1) // threads
+        jobs = []
+        for t in range(threads):
+            a, b = y0 + t * per, min(y1, y0 + (t + 1) * per)
+            if a >= b:
+                continue
+            th = threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, a, b, None, None, cnt[t]))
+            jobs.append(th)
+        t0 = time.perf_counter()
+        for th in jobs:
+            th.start()
+        for th in jobs:
+            th.join()
+        return time.perf_counter() - t0
+
+    mid = H // 2
+    t_probe = run(mid, mid + 1, 1)                                   # one row, one core
+    rows = int(budget_s * cores / max(t_probe, 1e-6))
+    rows = max(cores, min(rows - rows % cores, H - H % cores))
+    y0 = max(0, mid - rows // 2)
+    dt = run(y0, y0 + rows, cores)
+    samples = rows * W * spp
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"rows {y0}..{y0 + rows} of the same frame at {W}x{H}x{spp}, {rows * W} pixels, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--frame", type=int, default=98)
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--obj", type=str, default="")
+    ap.add_argument("--also-far", action="store_true", help="also time pose frame 0 (almost all background)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--stack-entries", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import dsrt_amd as d
+    from dsrt_amd import meshgen
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- scene: mesh -> flatten -> BVH (host), upload + re-layout (device).  Not timed. ----
+    W, H, spp, depth = args.width, args.height, args.spp, args.depth
+    if args.obj:
+        obj, mesh_name = args.obj, os.path.basename(args.obj)
+    else:
+        obj = f"/tmp/dsrt_bench_station_{args.tris}.obj"
+        if rank == 0 and not os.path.exists(obj):
+            tmp = obj + f".{os.getpid()}.tmp"
+            meshgen.write_obj(meshgen.build_station(args.tris), tmp, mtl_name=os.path.basename(obj)[:-4] + ".mtl")
+            os.replace(tmp, obj)
+        if world > 1:
+            dist.barrier()
+        mesh_name = f"procedural ISS-like stand-in (meshgen.py), target {args.tris} triangles"
+    hs = d.HostScene().add_obj(obj)
+    hs.build_bvh()
+    poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
+
+    ctx = d.Context(local_rank)
+
+    def frame_scene(idx):
+        fr = d.pose_to_frame(poses[idx])
+        cam = d.frame_camera(fr, 40.0, W, H, spp, depth)
+        return fr, cam, hs.view(cam, tuple(fr.sun_dir_model))
+
+    fr, cam, scene = frame_scene(args.frame)
+    ctx.upload(scene)
+    n_tris = scene.num_triangles
+
+    shard = n_gpus if n_gpus > 1 else 0
+    desc = d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard, stack_entries=args.stack_entries)
+    lay = d.shard_layout(desc)
+    part = torch.zeros(lay["rgb8_bytes_padded"] if shard else W * H * 3, dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(part) for _ in range(world)] if (shard and rank == 0) else None
+    gathered_flat = torch.zeros(world * part.numel(), dtype=torch.uint8, device=dev) if (shard and rank == 0) else None
+    image = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev) if shard and rank == 0 else part
+
+    kernel_ms = []
+
+    def step(collect=True):
+        st = ctx.render(desc, part.data_ptr(), stream=stream, want_stats=True)
+        if collect:
+            kernel_ms.append(st.kernel_ms)
+        if shard:
+            dist.gather(part, gathered, dst=0)
+            if rank == 0:
+                torch.cat(gathered, out=gathered_flat)
+                ctx.deinterleave(desc, gathered_flat.data_ptr(), image.data_ptr(), stream=stream)
+
+    def timed(steps, warmup):
+        kernel_ms.clear()
+        for _ in range(warmup):
+            step(collect=False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(args.steps, args.warmup)
+    my_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+
+    # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the roofline ----
+    cdesc = d.make_desc(W, H, spp, depth, shard_rank=desc.shard_rank, shard_count=desc.shard_count, collect_counters=1,
+                        stack_entries=args.stack_entries)
+    st = ctx.render(cdesc, part.data_ptr(), stream=stream, want_stats=True)
+    pixels_mine = lay["tiles_this_shard"] * 64 if shard else W * H
+    my_bytes = algorithmic_bytes(st, pixels_mine)
+    tot = torch.tensor([float(st.rays), float(st.primary_hits), float(st.samples), float(my_bytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    rays, primary_hits, samples_counted, _ = [float(v) for v in tot.tolist()]
+
+    far = None
+    if args.also_far and world == 1:
+        fr0, cam0, _ = frame_scene(0)
+        ctx.set_camera_sun(cam0, tuple(fr0.sun_dir_model))
+        dt0 = timed(args.steps, args.warmup)
+        st0 = ctx.render(cdesc, part.data_ptr(), stream=stream, want_stats=True)
+        far = {"frame": 0, "sep_m": fr0.sep_m, "value": W * H * spp * args.steps / dt0 / 1e6, "unit": "Msamples/s", "ms_per_step": dt0 / args.steps * 1e3,
+               "coverage": st0.primary_hits / max(1, st0.samples), "mrays_per_s": st0.rays * args.steps / dt0 / 1e6}
+        ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+
+    if rank == 0:
+        total_samples = W * H * spp
+        out = {
+            "metric": "Msamples/s (ISS-mesh frame, 1920x1080 @1000spp path-traced samples per second, whole job)",
+            "value": total_samples * args.steps / dt / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "mrays_per_s": rays * args.steps / dt / 1e6,
+            "config": {
+                "workload": f"{mesh_name}: {n_tris} triangles, pose frame {args.frame} of rendezvous_1s_dt0_01s.txt (camera {fr.sep_m:.1f} m), "
+                            f"{W}x{H} @ {spp} spp, max_depth {depth}, seed 1337, rng_mode 0 (reference LCG stream)",
+                "mesh_triangles": n_tris, "frame": args.frame, "width": W, "height": H, "spp": spp, "max_depth": depth,
+                "coverage": primary_hits / max(1.0, samples_counted), "rays_per_sample": rays / max(1.0, samples_counted),
+                "parallelism": f"screen tiles 8x8 interleaved over {n_gpus} GPU(s)" + (", one RCCL gather + de-interleave per step" if shard else ""),
+                "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": my_bytes / (my_kernel_ms * 1e-3) / 1e9 if my_kernel_ms > 0 else None,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": (my_bytes / (my_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if my_kernel_ms > 0 else None,
+                "traffic": None,
+                "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms, "algorithmic_bytes_per_launch": my_bytes,
+                "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path, "
+                        "working set sits in L2/Infinity Cache (SURVEY.md H6), so a low HBM fraction is expected",
+            },
+        }
+        if far:
+            out["far_frame"] = far
+        if n_gpus == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

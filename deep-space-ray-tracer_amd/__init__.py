@@ -8,6 +8,14 @@ import ctypes as C
 
 import numpy as np
 
+try:
+    # PyTorch-ROCm ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both see the GPU.  Importing torch
+    # first makes the dynamic loader bind libdsrt_hip.so to that same runtime (same SONAME).  torch is plumbing only
+    # (device buffers, streams, torch.distributed in bench.py); the library itself has no torch dependency.
+    import torch as _torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    _torch = None
+
 from . import capi
 from .capi import (DsrtFrame, DsrtPose, DsrtRenderDesc, DsrtStats, GPUCamera, GPUScene)
 

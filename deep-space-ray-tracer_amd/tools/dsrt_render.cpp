@@ -1,0 +1,108 @@
+// dsrt_render -- frame driver over the C ABI, taking the reference executable's flags.
+//
+// Mirrors what src/main.cpp of the reference does per run: --input_txt <pose file>, --output_dir <dir>
+// (:194-215), one frame per pose named frame_%04zu.ppm (:418-425), frames closer than 1 m skipped (:342-345),
+// camera at cam_in_model looking at the model origin with vfov 40 (:254-260, :399).  Differences, all deliberate:
+//   * the mesh path, image size, spp and depth are flags (--obj --width --height --spp --depth) instead of
+//     constants (:238, :255-258);
+//   * the scene is flattened, BVH-built and uploaded ONCE; only camera and sun change per frame (the reference
+//     rebuilds and re-uploads everything per frame, :405);
+//   * the output directory is created if missing but never emptied (the reference deletes its contents, :41-50);
+//   * PPM only: there is no ImageMagick shell-out (:28-36) and no upscaling step (:438-447).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/dsrt.h"
+
+static int fail(const char* what) {
+    std::fprintf(stderr, "dsrt_render: %s: %s\n", what, dsrt_last_error());
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    std::string pose_file, out_dir = "output", obj;
+    int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* flag) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "dsrt_render: %s needs a value\n", flag); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--input_txt") pose_file = next("--input_txt");
+        else if (a == "--output_dir") out_dir = next("--output_dir");
+        else if (a == "--obj") obj = next("--obj");
+        else if (a == "--width") width = std::atoi(next("--width"));
+        else if (a == "--height") height = std::atoi(next("--height"));
+        else if (a == "--spp") spp = std::atoi(next("--spp"));
+        else if (a == "--depth") depth = std::atoi(next("--depth"));
+        else if (a == "--frame") first = std::atoi(next("--frame"));
+        else if (a == "--frames") count = std::atoi(next("--frames"));
+        else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n]\n"); return 2; }
+    }
+    if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
+    mkdir(out_dir.c_str(), 0777);
+
+    std::vector<DsrtPose> poses;
+    if (!pose_file.empty()) {
+        int n = 0;
+        if (dsrt_read_pose_file(pose_file.c_str(), nullptr, 0, &n) == DSRT_OK) {
+            poses.resize((size_t)n);
+            dsrt_read_pose_file(pose_file.c_str(), poses.data(), n, &n);
+        }
+    }
+    if (poses.empty()) {                                   // the reference's default pose, src/main.cpp:275-284
+        std::printf("No valid pose file found; using single default pose.\n");
+        DsrtPose p{};
+        p.cam_pos_world[0] = 0.0; p.cam_pos_world[1] = 50.0; p.cam_pos_world[2] = 200.0;
+        p.model_pos_world[0] = 0.0; p.model_pos_world[1] = -100.0; p.model_pos_world[2] = 0.0;
+        poses.push_back(p);
+    } else {
+        std::printf("Loaded %zu poses.\n", poses.size());
+    }
+
+    DsrtHostScene* hs = dsrt_host_scene_create();
+    if (dsrt_host_scene_add_obj(hs, obj.c_str(), 1.0) != DSRT_OK) return fail("loading the mesh");
+    if (dsrt_host_scene_build_bvh(hs) != DSRT_OK) return fail("building the BVH");
+    GPUScene scene;
+    if (dsrt_host_scene_view(hs, &scene) != DSRT_OK) return fail("viewing the scene");
+    std::printf("mesh: %d triangles, %d BVH nodes, %d materials\n", scene.num_triangles, scene.num_bvh_nodes, scene.num_materials);
+
+    DsrtContext* ctx = nullptr;
+    if (dsrt_ctx_create(0, &ctx) != DSRT_OK) return fail("creating the device context");
+    bool uploaded = false;
+    std::vector<uint8_t> fb((size_t)width * height * 3);
+    const size_t last = count < 0 ? poses.size() : std::min(poses.size(), (size_t)(first + count));
+    for (size_t i = (size_t)first; i < last; ++i) {
+        DsrtFrame fr;
+        dsrt_pose_to_frame(&poses[i], &fr);
+        std::printf("\n=== Frame %zu ===\n  sep(cam, model) = %g m\n", i, fr.sep_m);
+        if (fr.skipped) { std::printf("  [!] Camera is inside/too close to ISS mesh. Skipping frame.\n"); continue; }
+        GPUCamera cam;
+        const float origin[3] = {0.0f, 0.0f, 0.0f};
+        if (dsrt_camera_look_at(&cam, fr.cam_in_model, origin, 40.0f, width, height, spp, depth) != DSRT_OK) return fail("camera");
+        if (!uploaded) {
+            dsrt_scene_set_frame(&scene, &cam, fr.sun_dir_model);
+            if (dsrt_scene_upload(ctx, &scene) != DSRT_OK) return fail("uploading the scene");
+            uploaded = true;
+        } else if (dsrt_scene_set_camera_sun(ctx, &cam, fr.sun_dir_model) != DSRT_OK) return fail("updating the camera");
+        DsrtRenderDesc d;
+        std::memset(&d, 0, sizeof d);
+        d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337;
+        DsrtStats st;
+        if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, &st) != DSRT_OK) return fail("rendering");
+        char name[64];
+        std::snprintf(name, sizeof name, "/frame_%04zu.ppm", i);
+        const std::string path = out_dir + name;
+        if (dsrt_write_ppm(path.c_str(), fb.data(), width, height) != DSRT_OK) return fail("writing the frame");
+        std::printf("  kernel %.3f ms (%.1f Msamples/s)\nSaved %s\n", st.kernel_ms, (double)width * height * spp / (st.kernel_ms * 1e3), path.c_str());
+    }
+    dsrt_ctx_destroy(ctx);
+    dsrt_host_scene_destroy(hs);
+    std::printf("Done.\n");
+    return 0;
+}

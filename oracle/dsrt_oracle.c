@@ -574,6 +574,17 @@ int dsrt_oracle_render_rows(const GPUScene* s, int W, int H, int y0, int y1, uin
     return 0;
 }
 
+int dsrt_oracle_bbox_hit(const float lo[3], const float hi[3], const float orig[3], const float dir[3], float t_min, float t_max) {
+    DsrtOracleCounters c;
+    memset(&c, 0, sizeof c);
+    GPUBVHNode n;
+    memset(&n, 0, sizeof n);
+    n.bbox_min.x = lo[0]; n.bbox_min.y = lo[1]; n.bbox_min.z = lo[2];
+    n.bbox_max.x = hi[0]; n.bbox_max.y = hi[1]; n.bbox_max.z = hi[2];
+    Ray r = { v3(orig[0], orig[1], orig[2]), v3(dir[0], dir[1], dir[2]) };
+    return bbox_hit(&n, &r, t_min, t_max, &c);
+}
+
 float dsrt_oracle_sinf(float x) { return dsrt_sinf(x); }
 float dsrt_oracle_cosf(float x) { return dsrt_cosf(x); }
 float dsrt_oracle_powf(float x, float y) { return dsrt_powf(x, y); }

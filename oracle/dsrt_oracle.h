@@ -71,6 +71,9 @@ float dsrt_oracle_rand01(uint32_t* state);
 int dsrt_oracle_scene_hit(const GPUScene* scene, const float orig[3], const float dir[3],
                           float t_min, float t_max, float out[9], int ids[4]);
 
+/* bbox_hit of src/gpu_render.cu:285-315 on one box (same algorithm as the reference's CPU aabb::hit, inc/aabb.h:33-56). */
+int dsrt_oracle_bbox_hit(const float lo[3], const float hi[3], const float orig[3], const float dir[3], float t_min, float t_max);
+
 /* The shared deterministic math, exposed so tests can compare device results bit for bit. */
 float dsrt_oracle_sinf(float x);
 float dsrt_oracle_cosf(float x);

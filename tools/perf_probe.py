@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Quick kernel timing sweep (development aid): frames x sizes on the procedural mesh, one line per run."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--frames", type=str, default="0,60,90,98")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--stack", type=str, default="0")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--counters", action="store_true")
+    a = ap.parse_args()
+    import dsrt_amd as d
+    from dsrt_amd import meshgen
+    obj = f"/tmp/dsrt_bench_station_{a.tris}.obj"
+    if not os.path.exists(obj):
+        meshgen.write_obj(meshgen.build_station(a.tris), obj)
+    hs = d.HostScene().add_obj(obj)
+    hs.build_bvh()
+    poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
+    ctx = d.Context(0)
+    up = False
+    W, H, spp = a.width, a.height, a.spp
+    for fi in [int(x) for x in a.frames.split(",")]:
+        fr = d.pose_to_frame(poses[fi])
+        cam = d.frame_camera(fr, 40.0, W, H, spp, 50)
+        if not up:
+            ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
+            up = True
+        else:
+            ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+        for K in [int(x) for x in a.stack.split(",")]:
+            best = None
+            for _ in range(a.reps):
+                _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K))
+                best = st.kernel_ms if best is None else min(best, st.kernel_ms)
+            rec = {"frame": fi, "sep_m": round(fr.sep_m, 1), "tris": hs.view().num_triangles, "WxHxspp": f"{W}x{H}x{spp}", "K": st.lds_stack_entries,
+                   "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
+            if a.counters:
+                _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1))
+                rec.update({"coverage": round(sc.primary_hits / sc.samples, 4), "rays_per_sample": round(sc.rays / sc.samples, 3),
+                            "Mrays_s": round(sc.rays / best / 1e3, 1), "nodes_per_ray": round(sc.nodes_entered / max(1, sc.rays), 2),
+                            "tris_per_ray": round(sc.tri_tests / max(1, sc.rays), 2), "max_stack": sc.max_stack, "spills": sc.stack_spills})
+            print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
