@@ -36,40 +36,46 @@ def algorithmic_bytes(st, pixels):
             24 * st.sphere_tests + 12 * st.tex_fetches + 3 * pixels)
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, the cgroup quota, and never more than the 16 a one-GPU box grants."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(d, scene, W, H, spp, budget_s):
-    """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: a band of rows around the
-    image centre at full spp, split over all host cores (each row range is independent)."""
+    """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: bands of rows around the image
+    centre at full spp, one row per thread per band, bands added until the time budget is used up."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
     orc = Oracle()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
 
-    def run(y0, y1, threads):
-        cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in range(threads)]
-        per = (y1 - y0 + threads - 1) // threads
-        jobs = []
-        for t in range(threads):
-            a, b = y0 + t * per, min(y1, y0 + (t + 1) * per)
-            if a >= b:
-                continue
-            th = threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, a, b, None, None, cnt[t]))
-            jobs.append(th)
-        t0 = time.perf_counter()
+    def band(y0):
+        cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in range(cores)]
+        jobs = [threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y0 + t, y0 + t + 1, None, None, cnt[t]))
+                for t in range(cores) if y0 + t < H]
         for th in jobs:
             th.start()
         for th in jobs:
             th.join()
-        return time.perf_counter() - t0
+        return len(jobs)
 
-    mid = H // 2
-    t_probe = run(mid, mid + 1, 1)                                   # one row, one core
-    rows = int(budget_s * cores / max(t_probe, 1e-6))
-    rows = max(cores, min(rows - rows % cores, H - H % cores))
-    y0 = max(0, mid - rows // 2)
-    dt = run(y0, y0 + rows, cores)
-    samples = rows * W * spp
-    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"rows {y0}..{y0 + rows} of the same frame at {W}x{H}x{spp}, {rows * W} pixels, {dt:.1f} s wall"}
+    rows, y = 0, max(0, H // 2 - cores)
+    t0 = time.perf_counter()
+    while True:
+        rows += band(y)
+        y += cores
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or y >= H:
+            break
+    return {"value": rows * W * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{rows} rows starting at row {max(0, H // 2 - cores)} of the same frame at {W}x{H}x{spp} ({rows * W} pixels), {dt:.1f} s wall"}
 
 
 def main():
