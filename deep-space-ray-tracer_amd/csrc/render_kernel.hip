@@ -510,98 +510,129 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         if (__all(state == ST_DONE)) break;
 
         // =====================================================================================
-        // TRAVERSE phase
+        // TRAVERSE phase ("while-while"): lanes at internal nodes step together; lanes that reached a leaf WAIT there
+        // until at least as many lanes are parked at leaves as are still descending, then all parked leaves are
+        // intersected together, one triangle index at a time, fully predicated.  Each lane still performs exactly the
+        // reference's sequence of box tests, triangle tests and pops -- only WHEN a lane runs changes, never what it does.
         // =====================================================================================
-        for (int iter = 0;; ++iter) {
+        for (int iter = 0;;) {
             const bool walking = (state == ST_TRAV_CLOSEST) || (state == ST_TRAV_SHADOW);
             const int n_walk = __popcll(__ballot(walking));
             if (n_walk == 0) break;
             const int n_wait = __popcll(__ballot(state < ST_TRAV_CLOSEST));
             if (iter >= kMinWalkIters && n_walk < n_wait) break;
-            if (!walking) continue;
 
-            bool finished = false;
-            if (++steps > kStepCap) { flags |= kFlagStepCap; finished = true; }
-            else if (!ref_is_leaf(cur)) {
-                // ---------------- internal node: both child boxes from one 64-byte record ----------------
-                if (CHECKED && (unsigned)cur >= (unsigned)S.num_pairs) { flags |= kFlagBadNodeRef; finished = true; }
-                else {
-                    const float4* rec = S.pairs + (size_t)cur * 4;
-                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-                    const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
-                    if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; }
-                    const F3 l_lo = mk(q0.x, q0.y, q0.z), l_hi = mk(q0.w, q1.x, q1.y);
-                    const F3 r_lo = mk(q1.z, q1.w, q2.x), r_hi = mk(q2.y, q2.z, q2.w);
-                    float tl, tr;
-                    const bool hl = slab(l_lo, l_hi, ro, rinv, closest, tl);
-                    const bool hr = slab(r_lo, r_hi, ro, rinv, closest, tr);
-                    if (hl && hr) {
-                        // nearer child by box centre along the ray :433-453
+            // ---------------- phase I: internal nodes ----------------
+            for (;;) {
+                const bool at_node = walking && cur >= 0 && cur != kRefNone;
+                const int n_node = __popcll(__ballot(at_node));
+                const int n_leaf = __popcll(__ballot(walking && cur < 0));
+                if (n_node == 0 || n_node < n_leaf) break;
+                ++iter;
+                if (at_node) {
+                    bool finished = false;
+                    if (++steps > kStepCap) { flags |= kFlagStepCap; finished = true; }
+                    else if (CHECKED && (unsigned)cur >= (unsigned)S.num_pairs) { flags |= kFlagBadNodeRef; finished = true; }
+                    else {
+                        const float4* rec = S.pairs + (size_t)cur * 4;
+                        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                        const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
+                        if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; }
+                        const F3 l_lo = mk(q0.x, q0.y, q0.z), l_hi = mk(q0.w, q1.x, q1.y);
+                        const F3 r_lo = mk(q1.z, q1.w, q2.x), r_hi = mk(q2.y, q2.z, q2.w);
+                        float tl, tr;
+                        const bool hl = slab(l_lo, l_hi, ro, rinv, closest, tl);
+                        const bool hr = slab(r_lo, r_hi, ro, rinv, closest, tr);
+                        // nearer child by box centre along the ray :433-453 (only decides anything when both are hit)
                         const F3 cl = mk(0.5f * (l_lo.x + l_hi.x), 0.5f * (l_lo.y + l_hi.y), 0.5f * (l_lo.z + l_hi.z));
                         const F3 cr = mk(0.5f * (r_lo.x + r_hi.x), 0.5f * (r_lo.y + r_hi.y), 0.5f * (r_lo.z + r_hi.z));
                         const float dl = dot(cl - ro, rd), dr = dot(cr - ro, rd);
                         const bool left_near = dl < dr;
-                        const int far_ref = left_near ? ref_r : ref_l;
-                        const float far_t = left_near ? tr : tl;
-                        cur = left_near ? ref_l : ref_r;
-                        const uint2 e = make_uint2((uint32_t)far_ref, __float_as_uint(far_t));
-                        if (sp < K) lds_stack[wave][sp][lane] = e;
-                        else if (sp - K < args.spill_entries) { args.spill[(size_t)(sp - K) * args.spill_stride + glane] = e; if (COUNT) c[C_STACK_SPILLS]++; }
-                        else { flags |= kFlagStackOverflow; finished = true; }
-                        sp++;
-                        if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
-                    } else if (hl) cur = ref_l;
-                    else if (hr) cur = ref_r;
-                    else cur = kRefNone;            // pop below
+                        if (hl && hr) {
+                            const int far_ref = left_near ? ref_r : ref_l;
+                            const float far_t = left_near ? tr : tl;
+                            cur = left_near ? ref_l : ref_r;
+                            const uint2 e = make_uint2((uint32_t)far_ref, __float_as_uint(far_t));
+                            if (sp < K) lds_stack[wave][sp][lane] = e;
+                            else if (sp - K < args.spill_entries) { args.spill[(size_t)(sp - K) * args.spill_stride + glane] = e; if (COUNT) c[C_STACK_SPILLS]++; }
+                            else { flags |= kFlagStackOverflow; finished = true; }
+                            sp++;
+                            if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
+                        } else if (hl) cur = ref_l;
+                        else if (hr) cur = ref_r;
+                        else {
+                            // pop: a postponed child is entered iff its entry distance is still in front of `closest`,
+                            // which is bbox_hit(node, ray, t_min, closest) for a box already known to be hit
+                            cur = kRefNone;
+                            for (;;) {
+                                if (sp == 0) { finished = true; break; }
+                                sp--;
+                                uint2 e = lds_stack[wave][sp < K ? sp : K - 1][lane];
+                                if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
+                                if (closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                            }
+                        }
+                    }
+                    if (finished) { cur = kRefNone; state = (state == ST_TRAV_CLOSEST) ? ST_SHADE : ST_SHADOW_DONE; }
                 }
-            } else {
-                // ---------------- leaf: its triangles in order :413-420 ----------------
-                int first = leaf_payload(cur), count = leaf_code(cur) + 1;
-                if (count == 8) {
-                    if (CHECKED && first >= S.num_big_leaves) { flags |= kFlagBadBigLeaf; first = 0; count = 0; }
-                    else { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
-                }
-                if (CHECKED && (first < 0 || first + count > S.num_tris)) { flags |= kFlagBadTriSlot; count = 0; }
-                if (COUNT) c[C_NODES_ENTERED]++;
-                for (int i = 0; i < count; ++i) {
-                    const int slot = first + i;
-                    const float4* tp = S.tri_isect + (size_t)slot * 3;
-                    const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                    if (COUNT) c[C_TRI_TESTS]++;
-                    // Moller-Trumbore :336-353
-                    const F3 v0 = mk(a0.x, a0.y, a0.z), e1 = mk(a0.w, a1.x, a1.y), e2 = mk(a1.z, a1.w, a2.x);
-                    const F3 pvec = cross(rd, e2);
-                    const float det = dot(e1, pvec);
-                    if (fabsf(det) < 1e-8f) continue;
-                    const float inv_det = 1.0f / det;
-                    const F3 tvec = ro - v0;
-                    const float u = dot(tvec, pvec) * inv_det;
-                    if (u < 0.0f || u > 1.0f) continue;
-                    const F3 qvec = cross(tvec, e1);
-                    const float v = dot(rd, qvec) * inv_det;
-                    if (v < 0.0f || u + v > 1.0f) continue;
-                    const float t = dot(e2, qvec) * inv_det;
-                    if (t < kTMin || t > closest) continue;
-                    closest = t; hit_slot = slot; hit_u = u; hit_v = v;
-                    if (COUNT) c[C_HIT_UPDATES]++;
-                    if (ANYHIT && state == ST_TRAV_SHADOW) { finished = true; break; }
-                }
-                cur = kRefNone;
             }
 
-            // ---------------- pop: a postponed child is entered iff its entry distance is still in front of `closest`,
-            //                  which is bbox_hit(node, ray, t_min, closest) for a box already known to be hit ----------
-            if (!finished && cur == kRefNone) {
-                for (;;) {
-                    if (sp == 0) { finished = true; break; }
-                    sp--;
-                    const uint2 e = (sp < K) ? lds_stack[wave][sp][lane] : args.spill[(size_t)(sp - K) * args.spill_stride + glane];
-                    if (closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+            // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
+            const bool at_leaf = ((state == ST_TRAV_CLOSEST) || (state == ST_TRAV_SHADOW)) && cur < 0;
+            if (__any(at_leaf)) {
+                ++iter;
+                int first = 0, count = 0;
+                bool finished = false;
+                if (at_leaf) {
+                    first = leaf_payload(cur);
+                    count = leaf_code(cur) + 1;
+                    if (count == 8) {
+                        if (CHECKED && first >= S.num_big_leaves) { flags |= kFlagBadBigLeaf; first = 0; count = 0; }
+                        else { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
+                    }
+                    if (CHECKED && (first < 0 || first + count > S.num_tris)) { flags |= kFlagBadTriSlot; count = 0; }
+                    if (++steps > kStepCap) { flags |= kFlagStepCap; count = 0; finished = true; }
+                    if (COUNT) c[C_NODES_ENTERED]++;
                 }
-            }
-            if (finished) {
-                cur = kRefNone;
-                state = (state == ST_TRAV_CLOSEST) ? ST_SHADE : ST_SHADOW_DONE;
+                for (int i = 0; __any(i < count); ++i) {
+                    if (i < count) {
+                        const int slot = first + i;
+                        const float4* tp = S.tri_isect + (size_t)slot * 3;
+                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                        if (COUNT) c[C_TRI_TESTS]++;
+                        // Moller-Trumbore :336-353, evaluated in full; the reference's early returns become one predicate.
+                        // Each `if (x) return false` is kept as `!(x)` so that NaNs fall the same way.
+                        const F3 v0 = mk(a0.x, a0.y, a0.z), e1 = mk(a0.w, a1.x, a1.y), e2 = mk(a1.z, a1.w, a2.x);
+                        const F3 pvec = cross(rd, e2);
+                        const float det = dot(e1, pvec);
+                        const float inv_det = 1.0f / det;
+                        const F3 tvec = ro - v0;
+                        const float u = dot(tvec, pvec) * inv_det;
+                        const F3 qvec = cross(tvec, e1);
+                        const float v = dot(rd, qvec) * inv_det;
+                        const float t = dot(e2, qvec) * inv_det;
+                        const bool accept = !(fabsf(det) < 1e-8f) && !(u < 0.0f) && !(u > 1.0f) && !(v < 0.0f) && !(u + v > 1.0f) &&
+                                            !(t < kTMin) && !(t > closest);
+                        if (accept) {
+                            closest = t; hit_slot = slot; hit_u = u; hit_v = v;
+                            if (COUNT) c[C_HIT_UPDATES]++;
+                            if (ANYHIT && state == ST_TRAV_SHADOW) { finished = true; count = 0; }
+                        }
+                    }
+                }
+                if (at_leaf) {
+                    cur = kRefNone;
+                    if (!finished) {
+                        for (;;) {
+                            if (sp == 0) { finished = true; break; }
+                            sp--;
+                            uint2 e = lds_stack[wave][sp < K ? sp : K - 1][lane];
+                                if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
+                            if (closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
+                        }
+                    }
+                    if (finished) { cur = kRefNone; state = (state == ST_TRAV_CLOSEST) ? ST_SHADE : ST_SHADOW_DONE; }
+                }
             }
         }
     }
