@@ -395,6 +395,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.spill = ctx->spill.p;
     a.spill_stride = (uint32_t)lanes;
     a.spill_entries = spill_entries;
+    a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 16;
+    a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
+    a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 4;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
@@ -417,6 +420,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->tri_tests = cnt[C_TRI_TESTS]; stats->hit_updates = cnt[C_HIT_UPDATES]; stats->sphere_tests = cnt[C_SPHERE_TESTS];
         stats->shaded_hits = cnt[C_SHADED_HITS]; stats->tex_fetches = cnt[C_TEX_FETCHES]; stats->stack_spills = cnt[C_STACK_SPILLS];
         stats->max_stack = cnt[C_MAX_STACK];
+        stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
         if (stats->device_flags) {
             char buf[96];
             std::snprintf(buf, sizeof buf, "render kernel raised status flags 0x%x", stats->device_flags);

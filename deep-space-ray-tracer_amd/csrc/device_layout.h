@@ -82,11 +82,15 @@ struct RenderArgs {
     uint2*    spill;           // stack overflow area: [(entry - K) * spill_stride + global lane]
     uint32_t  spill_stride;
     int       spill_entries;
+    int       min_walk_iters;  // a traverse phase runs at least this many steps before it may yield to waiting lanes
+    int       advance_budget;  // state transitions per lane per advance phase
+    int       leaf_ratio4;     // phase I yields to the leaf phase when 4 * lanes_at_nodes < leaf_ratio4 * lanes_at_leaves
 };
 
 // order matches the DsrtStats tail in include/dsrt.h
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
-               C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK, kNumCounters };
+               C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
+               C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE, kNumCounters };
 
 // status bits raised by the checked build
 constexpr uint32_t kFlagBadNodeRef = 1u, kFlagBadTriSlot = 2u, kFlagBadMaterial = 4u, kFlagStackOverflow = 8u,

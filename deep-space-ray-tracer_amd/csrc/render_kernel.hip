@@ -182,8 +182,6 @@ enum : int {
 };
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kAdvanceBudget = 12;          // state transitions per lane per advance phase
-constexpr int kMinWalkIters = 16;           // a traverse phase runs at least this many steps before it may yield to waiting lanes
 constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps than this (guards against corrupt input)
 
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT>
@@ -260,8 +258,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         // =====================================================================================
         // ADVANCE phase
         // =====================================================================================
-        for (int budget = 0; budget < kAdvanceBudget; ++budget) {
+        for (int budget = 0; budget < args.advance_budget; ++budget) {
             if (!__any(state < ST_TRAV_CLOSEST)) break;
+            if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             if (state == ST_FETCH) {
                 uint32_t item = atomicAdd(args.queue, 1u);
                 if (item >= P.total_items) {
@@ -520,15 +519,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
             const int n_walk = __popcll(__ballot(walking));
             if (n_walk == 0) break;
             const int n_wait = __popcll(__ballot(state < ST_TRAV_CLOSEST));
-            if (iter >= kMinWalkIters && n_walk < n_wait) break;
+            if (iter >= args.min_walk_iters && n_walk < n_wait) break;
 
             // ---------------- phase I: internal nodes ----------------
             for (;;) {
                 const bool at_node = walking && cur >= 0 && cur != kRefNone;
                 const int n_node = __popcll(__ballot(at_node));
                 const int n_leaf = __popcll(__ballot(walking && cur < 0));
-                if (n_node == 0 || n_node < n_leaf) break;
+                if (n_node == 0 || 4 * n_node < args.leaf_ratio4 * n_leaf) break;
                 ++iter;
+                if (COUNT) c[C_NODE_SLOTS]++;
                 if (at_node) {
                     bool finished = false;
                     if (++steps > kStepCap) { flags |= kFlagStepCap; finished = true; }
@@ -595,6 +595,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                     if (COUNT) c[C_NODES_ENTERED]++;
                 }
                 for (int i = 0; __any(i < count); ++i) {
+                    if (COUNT) c[C_TRI_SLOTS]++;
                     if (i < count) {
                         const int slot = first + i;
                         const float4* tp = S.tri_isect + (size_t)slot * 3;

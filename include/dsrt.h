@@ -131,10 +131,11 @@ typedef struct DsrtRenderDesc {
     int      tile_size;             /* screen-tile edge in pixels, multiple of 8; 0 -> 8          */
     int      shard_rank;            /* this process renders tiles t with t % shard_count == shard_rank */
     int      shard_count;           /* 0 or 1 -> whole image                                      */
-    int      collect_counters;      /* 1 -> run the counting build of the kernel, fill DsrtStats counters */
+    int      collect_counters;      /* 1 -> counting build of the kernel (fills DsrtStats); 2 -> counting build WITHOUT the any-hit
+                                       shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
-    int      reserved[3];
+    int      tune[3];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4} (see device_layout.h) */
 } DsrtRenderDesc;
 
 typedef struct DsrtStats {
@@ -144,6 +145,9 @@ typedef struct DsrtStats {
     int      lds_stack_entries;
     uint64_t samples, rays, primary_hits, box_fetches, nodes_entered, internal_entered, tri_tests, hit_updates,
              sphere_tests, shaded_hits, tex_fetches, stack_spills, max_stack;
+    /* lane-slot accounting of the counting build: every lane of a wave adds 1 per wave iteration of the node loop / the
+     * triangle loop / the advance loop, so active / slots is the SIMD utilisation of that loop */
+    uint64_t node_slots, tri_slots, adv_slots, adv_active;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of
