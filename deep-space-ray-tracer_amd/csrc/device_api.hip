@@ -25,6 +25,9 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
+hipError_t launch_wavefront(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+int wavefront_slots_per_block();
+size_t wavefront_state_words();
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -217,6 +220,7 @@ struct DsrtContext {
     PackedScene scene;
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
+    DevBuf<uint32_t> wf_state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 };
@@ -382,10 +386,22 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     if (K != 8 && K != 12 && K != 16 && K != 24) { set_error("dsrt_render: stack_entries must be 8, 12, 16 or 24"); return DSRT_ERR_INVALID; }
     if (desc->stack_entries <= 0 && sc.view.stack_need <= 8) K = 8;
 
-    const int threads_per_block = 64 * kernel_waves_per_block();
-    int blocks = ctx->num_cus * 8;
-    const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
-    if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
+    const int variant = desc->variant == 0 ? 1 : desc->variant;
+    if (variant != 1 && variant != 2) { set_error("dsrt_render: unknown kernel variant"); return DSRT_ERR_INVALID; }
+    const int threads_per_block = variant == 2 ? 256 : 64 * kernel_waves_per_block();
+    int blocks;
+    if (variant == 2) {
+        blocks = ctx->num_cus * 4;
+        const long long needed = ((long long)f.total_items + wavefront_slots_per_block() - 1) / wavefront_slots_per_block();
+        if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
+        const size_t words = (size_t)blocks * wavefront_state_words();
+        if (ctx->wf_state.n < words) { int rc = ctx->wf_state.alloc(words); if (rc) return rc; }
+        a.wf_state = ctx->wf_state.p;
+    } else {
+        blocks = ctx->num_cus * 8;
+        const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
+        if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
+    }
     const int spill_entries = sc.view.stack_need > K ? sc.view.stack_need - K : 0;
     const size_t lanes = (size_t)blocks * threads_per_block;
     if (spill_entries > 0 && ctx->spill.n < lanes * (size_t)spill_entries) {
@@ -402,7 +418,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    if (variant == 2) HIP_TRY(launch_wavefront(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    else HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -411,7 +428,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         uint32_t ctrl[kCtrlWords];
         HIP_TRY(hipMemcpy(ctrl, ctx->ctrl.p, sizeof ctrl, hipMemcpyDeviceToHost));
         stats->device_flags = ctrl[1];
-        stats->waves_launched = blocks * kernel_waves_per_block();
+        stats->waves_launched = blocks * (threads_per_block / 64);
         stats->lds_stack_entries = K;
         uint64_t cnt[kNumCounters];
         std::memcpy(cnt, &ctrl[4], sizeof cnt);

@@ -84,6 +84,7 @@ struct RenderArgs {
     int       spill_entries;
     int       min_walk_iters;  // a traverse phase runs at least this many steps before it may yield to waiting lanes
     int       advance_budget;  // state transitions per lane per advance phase
+    uint32_t* wf_state;        // wavefront kernel: per-workgroup strips of pixel-slot state
     int       leaf_ratio4;     // phase I yields to the leaf phase when 4 * lanes_at_nodes < leaf_ratio4 * lanes_at_leaves
 };
 

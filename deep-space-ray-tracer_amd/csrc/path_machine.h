@@ -1,0 +1,335 @@
+// path_machine.h -- one pixel's path as a small state machine; the render kernels differ only in how they schedule it.
+//
+// States (what the lane needs next):
+//   ST_FETCH        a pixel from the work queue                  ST_GEN          start the next sample / finish the pixel
+//   ST_BOUNCE       top of ray_color's depth loop (:727-744)     ST_SHADE        closest-hit result is in (hit_slot, closest, u, v)
+//   ST_SHADOW_DONE  shadow-ray result is in hit_slot             ST_TRAV_*       a ray is ready / being walked through the BVH
+// advance_step() performs exactly ONE transition of a lane whose state is < ST_TRAV_CLOSEST.
+#pragma once
+
+#include "device_math.h"
+
+namespace dsrt {
+
+enum : int {
+    ST_FETCH = 0, ST_GEN = 1, ST_BOUNCE = 2, ST_SHADE = 3, ST_SHADOW_DONE = 4,                      // advance-phase states
+    ST_TRAV_CLOSEST = 8, ST_TRAV_SHADOW = 9,                                                         // traverse-phase states
+    ST_DONE = 16
+};
+
+constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps than this (guards against corrupt input)
+
+struct Lane {
+    int state = ST_FETCH;
+    int px = 0, ky = 0, sample = 0, depth = 0;
+    uint32_t out_index = 0, rng = 0;
+    F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
+    F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
+    int cur = kRefNone, sp = 0, hit_slot = -1;
+    float closest = kTMax, hit_u = 0.0f, hit_v = 0.0f;
+    uint32_t steps = 0;
+    // postponed continuation while the shadow ray is in flight
+    F3 pend_contrib = {0, 0, 0}, pend_thr = {0, 0, 0}, pend_o = {0, 0, 0}, pend_d = {0, 0, 0};
+    bool pend_end = false;
+};
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const RenderArgs& args, uint32_t* c) {
+    if (COUNT) {
+#pragma unroll
+        for (int i = 0; i < kNumCounters; ++i) {
+            if (i == C_MAX_STACK) atomicMax((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
+            else if (c[i]) atomicAdd((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
+            if (i != C_MAX_STACK) c[i] = 0;
+        }
+    }
+}
+
+template <bool COUNT, bool CHECKED, bool ANYHIT>
+__device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, uint32_t* c, uint32_t& flags) {
+    const DeviceScene& S = args.scene;
+    const FrameParams& P = args.frame;
+    int& state = ln.state; int& px = ln.px; int& ky = ln.ky; int& sample = ln.sample; int& depth = ln.depth;
+    uint32_t& out_index = ln.out_index; uint32_t& rng = ln.rng;
+    F3& accum = ln.accum; F3& thr = ln.thr; F3& L = ln.L; F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
+    int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
+    float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v;
+    uint32_t& steps = ln.steps;
+    F3& pend_contrib = ln.pend_contrib; F3& pend_thr = ln.pend_thr; F3& pend_o = ln.pend_o; F3& pend_d = ln.pend_d;
+    bool& pend_end = ln.pend_end;
+    const int spp = P.spp;
+    const int W = P.width, H = P.height;
+
+    // ray_color's return and the accumulate in render_kernel: clamp the SAMPLE to [0,1] (:935), add (:999), next sample.
+    auto end_sample = [&]() {
+        accum = accum + clamp01(L);
+        sample++;
+        state = ST_GEN;
+    };
+
+    // Set up the traversal of the ray in (ro, rd).  Mirrors the head of bvh_hit_closest :394-410: the root box is
+    // tested first; a miss means the BVH contributes nothing and the lane goes straight to `after`.
+    auto start_ray = [&](int trav_state, int after) {
+        if (COUNT) c[C_RAYS]++;
+        rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        closest = kTMax;
+        hit_slot = -1;
+        sp = 0;
+        steps = 0;
+        state = after;
+        if (S.root_ref != kRefNone) {
+            if (COUNT) c[C_BOX_FETCHES]++;
+            float t_entry;
+            if (slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state = trav_state; }
+        }
+        // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
+        if (state == ST_SHADE && S.num_spheres == 0) end_sample();
+    };
+
+    if (state == ST_FETCH) {
+        uint32_t item = atomicAdd(args.queue, 1u);
+        if (item >= P.total_items) {
+            state = ST_DONE;
+        } else {
+            const uint32_t tt = (uint32_t)(P.tile * P.tile);
+            const uint32_t k = item / tt, within = item % tt;
+            const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
+            const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
+            const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;
+            const uint32_t in_x = (sub % per_row) * 8u + (l & 7u), in_y = (sub / per_row) * 8u + (l >> 3);
+            const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
+            if (x < W && row < H) {
+                px = x;
+                ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
+                out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
+                rng = (uint32_t)(px + ky * W) ^ P.seed32;       // :990
+                accum = mk(0, 0, 0);
+                sample = 0;
+                state = ST_GEN;
+            }
+        }
+    } else if (state == ST_GEN) {
+        if (sample >= spp) {
+            // tone map + store :1003-1030
+            float inv_spp = 1.0f / (float)spp;
+            F3 col = accum * inv_spp;
+            col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
+            col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
+            col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
+            col = clamp01(col);
+            const size_t o = (size_t)out_index * 3;
+            args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
+            args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
+            args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
+            if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
+            flush_counters<COUNT>(args, c);
+            state = ST_FETCH;
+        } else {
+            float jx = ((float)sample + rand01(rng)) / (float)spp;          // :995-996
+            float jy = ((float)sample + rand01(rng)) / (float)spp;
+            float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
+            float v = ((float)ky + jy) / (float)(H - 1);
+            const F3 cam_o = ld3(P.cam_origin), cam_llc = ld3(P.cam_llc), cam_h = ld3(P.cam_horizontal), cam_v = ld3(P.cam_vertical);
+            ro = cam_o;
+            rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
+            depth = 0;
+            L = mk(0, 0, 0);
+            thr = mk(1, 1, 1);
+            if (COUNT) c[C_SAMPLES]++;
+            start_ray(ST_TRAV_CLOSEST, ST_SHADE);      // depth 0: no roulette, max_depth >= 1 (host guarantees)
+        }
+    } else if (state == ST_BOUNCE) {
+        // top of the depth loop :727-744
+        bool go = depth < P.max_depth;
+        if (go && depth >= 5) {
+            float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+            p = fminf(p, 0.95f);
+            if (rand01(rng) > p) go = false;
+            else thr = thr * (1.0f / p);
+        }
+        if (!go) end_sample();
+        else start_ray(ST_TRAV_CLOSEST, ST_SHADE);
+    } else if (state == ST_SHADE) {
+        // ---- finish scene_hit :516-551: triangle record from (slot, t, u, v), then the spheres ----
+        bool hit_any = false;
+        F3 hp = mk(0, 0, 0), hn = mk(0, 0, 0);
+        int mat_id = 0, tex_id = -1;
+        bool front = true;
+        if (hit_slot >= 0) {
+            const float4* sh = S.tri_shade + (size_t)hit_slot * 3;
+            const float4 a0 = sh[0], a1 = sh[1], a2 = sh[2];
+            const float t = closest;
+            hp = mk(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);
+            const float wgt = 1.0f - hit_u - hit_v;                                          // :359-369
+            F3 n = ((mk(a0.x, a0.y, a0.z) * wgt) + (mk(a0.w, a1.x, a1.y) * hit_u)) + (mk(a1.z, a1.w, a2.x) * hit_v);
+            n = normalize(n);
+            front = dot(rd, n) < 0.0f;
+            hn = front ? n : (n * -1.0f);
+            mat_id = __float_as_int(a2.y);
+            tex_id = __float_as_int(a2.z);
+            hit_any = true;
+        }
+        for (int i = 0; i < S.num_spheres; ++i) {
+            if (COUNT) c[C_SPHERE_TESTS]++;
+            const GPUSphere sph = S.spheres[i];
+            float t_hit; F3 n_hit;
+            if (hit_sphere(sph, ro, rd, closest, t_hit, n_hit)) {
+                hit_any = true;
+                closest = t_hit;
+                hp = mk(ro.x + t_hit * rd.x, ro.y + t_hit * rd.y, ro.z + t_hit * rd.z);
+                front = dot(rd, n_hit) < 0.0f;
+                hn = front ? n_hit : (n_hit * -1.0f);
+                mat_id = sph.material_id;
+                tex_id = -1;
+            }
+        }
+        if (!hit_any) {
+            end_sample();                                                                     // :744-747
+        } else {
+            if (COUNT) { c[C_SHADED_HITS]++; if (depth == 0) c[C_PRIMARY_HITS]++; }
+            if (CHECKED && (unsigned)mat_id >= (unsigned)S.num_materials) { flags |= kFlagBadMaterial; mat_id = 0; }
+            const float4* mp = S.materials + (size_t)mat_id * 3;
+            const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+            const int mtype = __float_as_int(m0.x);
+            if (mtype == MAT_DIFFUSE_LIGHT) {                                                 // :754-758
+                L = L + (thr * mk(m1.w, m2.x, m2.y));
+                end_sample();
+            } else {
+                F3 albedo = mk(m1.x, m1.y, m1.z);                                             // :763-774
+                if (tex_id >= 0 && S.tri_uv) {
+                    const float4* uvp = S.tri_uv + (size_t)hit_slot * 2;
+                    const float4 u0 = uvp[0], u1 = uvp[1];
+                    const float wgt = 1.0f - hit_u - hit_v;
+                    const float u_tex = wgt * u0.x + hit_u * u0.z + hit_v * u1.x;
+                    const float v_tex = wgt * u0.y + hit_u * u0.w + hit_v * u1.y;
+                    albedo = albedo * tex2d(S, tex_id, u_tex, v_tex, c[C_TEX_FETCHES]);
+                }
+                if (mtype == MAT_DIELECTRIC) {                                               // scatter_dielectric :621-661
+                    float eta = m2.w;
+                    if (eta <= 0.0f || !isfinite(eta)) eta = 1.5f;
+                    const float ratio = front ? (1.0f / eta) : eta;
+                    const F3 unit = normalize(rd);
+                    const float cos_t = fminf(dot(unit * -1.0f, hn), 1.0f);
+                    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+                    const bool cannot = ratio * sin_t > 1.0f;
+                    const float rprob = schlick(cos_t, ratio);
+                    F3 dir;
+                    if (cannot || rprob > rand01(rng)) dir = reflect(unit, hn);
+                    else dir = refract(unit, hn, ratio);
+                    ro = hp; rd = dir;                      // attenuation is (1,1,1): throughput unchanged
+                    depth++;
+                    state = ST_BOUNCE;
+                } else if (mtype == MAT_METAL) {                                             // scatter_metal :603-619
+                    const F3 refl = reflect(normalize(rd), hn);
+                    const float fuzz = fmaxf(0.0f, fminf(1.0f, m2.z));
+                    const F3 dir = refl + (random_in_unit_sphere(rng) * fuzz);
+                    if (dot(dir, hn) > 0.0f) {
+                        thr = thr * albedo;
+                        ro = hp; rd = dir;
+                        depth++;
+                        state = ST_BOUNCE;
+                    } else {
+                        end_sample();
+                    }
+                } else {
+                    // ---- Lambertian: sun next-event estimation :800-836 ----
+                    bool need_shadow = false;
+                    F3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0);
+                    if (P.sun_enabled) {
+                        const F3 Ldir = normalize(mk(-P.sun_dir[0], -P.sun_dir[1], -P.sun_dir[2]));
+                        const float cos_t = fmaxf(0.0f, dot(hn, Ldir));
+                        if (cos_t > 0.0f) {
+                            sh_o = hp + (hn * 1e-3f);
+                            sh_d = Ldir;
+                            const float pdf_brdf = cos_t / kPi;
+                            const float pdf_mix = 0.5f * 1.0f + 0.5f * pdf_brdf;
+                            const float weight = (cos_t / kPi) / pdf_mix;
+                            pend_contrib = thr * (albedo * (ld3(P.sun_radiance) * weight));
+                            need_shadow = true;
+                        }
+                    }
+                    // ---- next direction.  The shadow ray draws no random numbers, so sampling the bounce
+                    //      before tracing it leaves the LCG stream exactly as the reference's order does. ----
+                    bool end_after = false;
+                    F3 ndir = mk(0, 0, 1), nthr = thr;
+                    if (S.num_lights == 0) {                                                 // :852-866
+                        float pdf;
+                        ndir = sample_cosine_hemisphere(hn, rng, pdf);
+                        if (pdf <= 0.0f) end_after = true;
+                        else {
+                            const float cos_t = fmaxf(0.0f, dot(ndir, hn));
+                            const float spdf = cos_t / kPi;
+                            nthr = thr * (albedo * (spdf / pdf));
+                        }
+                    } else {                                                                 // :871-932
+                        float pdf_val = 0.0f;
+                        const float choose = rand01(rng);
+                        if (choose < 0.5f) {
+                            int k = (int)(rand01(rng) * (float)S.num_lights);
+                            if (k >= S.num_lights) k = S.num_lights - 1;
+                            int found = 0, light_idx = 0;
+                            for (int i = 0; i < S.num_spheres; ++i) {
+                                const float4* lm = S.materials + (size_t)S.spheres[i].material_id * 3;
+                                const float4 l0 = lm[0], l1 = lm[1], l2 = lm[2];
+                                if (__float_as_int(l0.x) == MAT_DIFFUSE_LIGHT && (l1.w > 0 || l2.x > 0 || l2.y > 0)) {
+                                    if (found == k) { light_idx = i; break; }
+                                    found++;
+                                }
+                            }
+                            float pdf_lc = 0.0f;
+                            sample_sphere_light(S.spheres[light_idx], hp, rng, ndir, pdf_lc);
+                            if (pdf_lc <= 0.0f) end_after = true;
+                            else {
+                                const float cos_t = fmaxf(0.0f, dot(ndir, hn));
+                                if (cos_t <= 0.0f) end_after = true;
+                                else {
+                                    const float pdf_light = pdf_lc / (float)S.num_lights;
+                                    const float pdf_brdf = cos_t / kPi;
+                                    pdf_val = 0.5f * pdf_light + 0.5f * pdf_brdf;
+                                }
+                            }
+                        } else {
+                            float pdf_brdf = 0.0f;
+                            ndir = sample_cosine_hemisphere(hn, rng, pdf_brdf);
+                            if (pdf_brdf <= 0.0f) end_after = true;
+                            else pdf_val = 0.5f * pdf_brdf;
+                        }
+                        if (!end_after) {
+                            const float cos_t = fmaxf(0.0f, dot(ndir, hn));
+                            const float spdf = cos_t / kPi;
+                            nthr = thr * (albedo * (spdf / pdf_val));
+                        }
+                    }
+                    if (need_shadow) {
+                        pend_end = end_after; pend_thr = nthr; pend_o = hp; pend_d = ndir;
+                        ro = sh_o; rd = sh_d;
+                        start_ray(ST_TRAV_SHADOW, ST_SHADOW_DONE);
+                    } else if (end_after) {
+                        end_sample();
+                    } else {
+                        thr = nthr; ro = hp; rd = ndir;
+                        depth++;
+                        state = ST_BOUNCE;
+                    }
+                }
+            }
+        }
+    } else if (state == ST_SHADOW_DONE) {
+        // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
+        bool blocked = hit_slot >= 0;
+        if (!blocked || !ANYHIT) {
+            for (int i = 0; i < S.num_spheres; ++i) {
+                if (COUNT) c[C_SPHERE_TESTS]++;
+                float t_hit; F3 n_hit;
+                if (hit_sphere(S.spheres[i], ro, rd, closest, t_hit, n_hit)) { blocked = true; closest = t_hit; }
+            }
+        } else if (COUNT) {
+            c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
+        }
+        if (!blocked) L = L + pend_contrib;
+        if (pend_end) end_sample();
+        else { thr = pend_thr; ro = pend_o; rd = pend_d; depth++; state = ST_BOUNCE; }
+    }
+}
+
+}  // namespace dsrt

@@ -24,235 +24,28 @@
 //     and shadow rays stop at the first accepted triangle (same boolean as the reference's closest-hit search).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: IEEE div/sqrt are part of the contract).
-#include "device_layout.h"
-#include "../../include/dsrt_detmath.h"
+#include "path_machine.h"
 
 namespace dsrt {
-
-struct F3 { float x, y, z; };
-__device__ __forceinline__ F3 mk(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ F3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
-__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ F3 operator*(F3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ F3 cross(F3 a, F3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ F3 normalize(F3 a) {                 // f3_norm :51-56
-    float L = sqrtf(dot(a, a));
-    if (L <= 0.0f) return mk(0.0f, 0.0f, 0.0f);
-    float inv = 1.0f / L;
-    return mk(a.x * inv, a.y * inv, a.z * inv);
-}
-__device__ __forceinline__ F3 clamp01(F3 a) {
-    return mk(fminf(1.0f, fmaxf(0.0f, a.x)), fminf(1.0f, fmaxf(0.0f, a.y)), fminf(1.0f, fmaxf(0.0f, a.z)));
-}
-
-constexpr float kPi = 3.14159265358979323846f;                  // PI_F :96
-constexpr float kTMin = 0.001f, kTMax = 1e9f;                   // scene_hit(ray, 0.001f, 1e9f) :744, :816
-
-__device__ __forceinline__ float rand01(uint32_t& s) {          // :77-80
-    s = s * 1664525u + 1013904223u;
-    return (float)(s & 0x00FFFFFFu) / 16777216.0f;
-}
-
-__device__ __forceinline__ F3 random_in_unit_sphere(uint32_t& rng) {   // :82-91
-    for (;;) {
-        float x = rand01(rng) * 2.0f - 1.0f;
-        float y = rand01(rng) * 2.0f - 1.0f;
-        float z = rand01(rng) * 2.0f - 1.0f;
-        F3 p = mk(x, y, z);
-        if (dot(p, p) >= 1.0f) continue;
-        return p;
-    }
-}
-
-// sample_cosine_hemisphere :121-141 with build_onb :112-118 and random_cosine_direction :99-109
-__device__ __forceinline__ F3 sample_cosine_hemisphere(F3 normal, uint32_t& rng, float& pdf) {
-    F3 w = normalize(normal);
-    F3 a = (fabsf(w.x) > 0.9f) ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-    F3 v = normalize(cross(w, a));
-    F3 u = cross(v, w);
-    float r1 = rand01(rng);
-    float r2 = rand01(rng);
-    float lz = sqrtf(1.0f - r2);
-    float phi = 2.0f * kPi * r1;
-    float lx = dsrt_cosf(phi) * sqrtf(r2);
-    float ly = dsrt_sinf(phi) * sqrtf(r2);
-    F3 d = normalize(((u * lx) + (v * ly)) + (w * lz));
-    float c = fmaxf(0.0f, dot(d, normal));
-    pdf = (c > 0.0f) ? (c / kPi) : 0.0f;
-    return d;
-}
-
-// sample_sphere_light_direction :145-189
-__device__ __forceinline__ void sample_sphere_light(const GPUSphere& sph, F3 origin, uint32_t& rng, F3& dir, float& pdf) {
-    float z = 2.0f * rand01(rng) - 1.0f;
-    float phi = 2.0f * kPi * rand01(rng);
-    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
-    float x = r * dsrt_cosf(phi);
-    float y = r * dsrt_sinf(phi);
-    F3 center = mk(sph.center.x, sph.center.y, sph.center.z);
-    F3 p_light = center + (mk(x, y, z) * sph.radius);
-    F3 to_light = p_light - origin;
-    float dist2 = dot(to_light, to_light);
-    float dist = sqrtf(dist2);
-    if (dist <= 0.0f) { pdf = 0.0f; dir = mk(0.0f, 0.0f, 1.0f); return; }
-    F3 wi = to_light * (1.0f / dist);
-    F3 n_light = normalize(p_light - center);
-    float cos_l = fmaxf(0.0f, dot(n_light, wi * -1.0f));
-    if (cos_l <= 0.0f) { pdf = 0.0f; dir = wi; return; }
-    float area = 4.0f * kPi * sph.radius * sph.radius;
-    pdf = dist2 / (cos_l * area);
-    dir = wi;
-}
-
-__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - (n * (2.0f * dot(v, n))); }      // :195
-__device__ __forceinline__ F3 refract(F3 v, F3 n, float eta) {                                    // :199-206
-    F3 uv = normalize(v);
-    float c = fminf(dot(uv * -1.0f, n), 1.0f);
-    F3 perp = (uv + (n * c)) * eta;
-    F3 par = n * (-sqrtf(fabsf(1.0f - dot(perp, perp))));
-    return perp + par;
-}
-__device__ __forceinline__ float schlick(float cosine, float ref_idx) {                          // :208-212
-    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-    r0 = r0 * r0;
-    return r0 + (1.0f - r0) * dsrt_powf(1.0f - cosine, 5.0f);
-}
-
-// One box of bbox_hit :285-315 against a ray whose 1/dir is hoisted (same division, done once per ray).
-// Returns hit and the entry distance tmin = max(t_min, t0x, t0y, t0z).
-//   The reference walks the axes with `t_min = t0 > t_min ? t0 : t_min; t_max = t1 < t_max ? t1 : t_max;
-//   if (t_max <= t_min) return false;`.  t_min only grows and t_max only shrinks, so failing after any axis implies
-//   failing after the last, and the result is `!(tmax_final <= tmin_final)`.  A NaN t0/t1 (0 * inf, ray origin on a
-//   slab plane with a zero direction component) loses both of the reference's comparisons and leaves the bound
-//   unchanged -- which is what fmaxf/fminf do with one NaN operand; the running bounds themselves are never NaN.
-//   +0/-0 differences cannot matter: the bounds are only ever compared.
-__device__ __forceinline__ bool slab(F3 lo, F3 hi, F3 o, F3 inv, float t_max, float& t_entry) {
-    float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
-    float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
-    float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
-    float t0x = inv.x < 0.0f ? bx : ax, t1x = inv.x < 0.0f ? ax : bx;
-    float t0y = inv.y < 0.0f ? by : ay, t1y = inv.y < 0.0f ? ay : by;
-    float t0z = inv.z < 0.0f ? bz : az, t1z = inv.z < 0.0f ? az : bz;
-    float tmin = fmaxf(fmaxf(kTMin, t0x), fmaxf(t0y, t0z));
-    float tmax = fminf(fminf(t_max, t1x), fminf(t1y, t1z));
-    t_entry = tmin;
-    return !(tmax <= tmin);
-}
-
-__device__ __forceinline__ bool hit_sphere(const GPUSphere& sph, F3 o, F3 d, float t_max, float& t_out, F3& n_out) {   // :478-504
-    F3 center = mk(sph.center.x, sph.center.y, sph.center.z);
-    F3 oc = o - center;
-    float a = dot(d, d);
-    float half_b = dot(oc, d);
-    float c = dot(oc, oc) - sph.radius * sph.radius;
-    float disc = half_b * half_b - a * c;
-    if (disc < 0.0f) return false;
-    float sq = sqrtf(disc);
-    float root = (-half_b - sq) / a;
-    if (root < kTMin || root > t_max) {
-        root = (-half_b + sq) / a;
-        if (root < kTMin || root > t_max) return false;
-    }
-    t_out = root;
-    F3 p = mk(o.x + root * d.x, o.y + root * d.y, o.z + root * d.z);
-    n_out = (p - center) * (1.0f / sph.radius);
-    return true;
-}
-
-__device__ __forceinline__ F3 tex2d(const DeviceScene& s, int tex_id, float u, float v, uint32_t& n_fetch) {           // :232-259
-    if (tex_id < 0 || tex_id >= s.num_textures || !s.tex_headers || !s.tex_pool) return mk(1.0f, 1.0f, 1.0f);
-    GPUTextureHeader th = s.tex_headers[tex_id];
-    u = u - floorf(u);
-    v = v - floorf(v);
-    int i = (int)(u * (float)(th.width - 1));
-    int j = (int)((1.0f - v) * (float)(th.height - 1));
-    int idx = th.offset + (j * th.width + i) * 3;
-    if (idx < 0 || idx + 2 >= s.tex_pool_floats) return mk(1.0f, 1.0f, 1.0f);
-    n_fetch++;
-    return mk(s.tex_pool[idx + 0], s.tex_pool[idx + 1], s.tex_pool[idx + 2]);
-}
-
-enum : int {
-    ST_FETCH = 0, ST_GEN = 1, ST_BOUNCE = 2, ST_SHADE = 3, ST_SHADOW_DONE = 4,                      // advance-phase states
-    ST_TRAV_CLOSEST = 8, ST_TRAV_SHADOW = 9,                                                         // traverse-phase states
-    ST_DONE = 16
-};
-
 constexpr int kWavesPerBlock = 4;
-constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps than this (guards against corrupt input)
 
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const RenderArgs args) {
     const DeviceScene& S = args.scene;
-    const FrameParams& P = args.frame;
     __shared__ uint2 lds_stack[kWavesPerBlock][K][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
 
-    // ---- lane state ----
-    int state = ST_FETCH;
-    int px = 0, ky = 0, sample = 0, depth = 0;
-    uint32_t out_index = 0, rng = 0;
-    F3 accum = mk(0, 0, 0), thr = mk(1, 1, 1), L = mk(0, 0, 0);
-    F3 ro = mk(0, 0, 0), rd = mk(0, 0, 1), rinv = mk(0, 0, 0);
-    int cur = kRefNone, sp = 0, hit_slot = -1;
-    float closest = kTMax, hit_u = 0.0f, hit_v = 0.0f;
-    uint32_t steps = 0;
-    // postponed continuation while the shadow ray is in flight
-    F3 pend_contrib = mk(0, 0, 0), pend_thr = mk(0, 0, 0), pend_o = mk(0, 0, 0), pend_d = mk(0, 0, 0);
-    bool pend_end = false;
-    // counters (counting build)
+    Lane ln;
+    int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
+    float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v; uint32_t& steps = ln.steps;
+    F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
     uint32_t c[kNumCounters];
 #pragma unroll
     for (int i = 0; i < kNumCounters; ++i) c[i] = 0;
     uint32_t flags = 0;
-
-    const int spp = P.spp;
-    const int W = P.width, H = P.height;
-    const F3 cam_o = ld3(P.cam_origin), cam_llc = ld3(P.cam_llc), cam_h = ld3(P.cam_horizontal), cam_v = ld3(P.cam_vertical);
-    const F3 root_lo = ld3(S.root_lo), root_hi = ld3(S.root_hi);
-
-    auto flush_counters = [&]() {
-        if (COUNT) {
-#pragma unroll
-            for (int i = 0; i < kNumCounters; ++i) {
-                if (i == C_MAX_STACK) atomicMax((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
-                else if (c[i]) atomicAdd((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
-                if (i != C_MAX_STACK) c[i] = 0;
-            }
-        }
-    };
-
-    // ray_color's return and the accumulate in render_kernel: clamp the SAMPLE to [0,1] (:935), add (:999), next sample.
-    auto end_sample = [&]() {
-        accum = accum + clamp01(L);
-        sample++;
-        state = ST_GEN;
-    };
-
-    // Set up the traversal of the ray in (ro, rd).  Mirrors the head of bvh_hit_closest :394-410: the root box is
-    // tested first; a miss means the BVH contributes nothing and the lane goes straight to `after`.
-    auto start_ray = [&](int trav_state, int after) {
-        if (COUNT) c[C_RAYS]++;
-        rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        closest = kTMax;
-        hit_slot = -1;
-        sp = 0;
-        steps = 0;
-        state = after;
-        if (S.root_ref != kRefNone) {
-            if (COUNT) c[C_BOX_FETCHES]++;
-            float t_entry;
-            if (slab(root_lo, root_hi, ro, rinv, closest, t_entry)) { cur = S.root_ref; state = trav_state; }
-        }
-        // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
-        if (state == ST_SHADE && S.num_spheres == 0) end_sample();
-    };
 
     for (;;) {
         // =====================================================================================
@@ -261,249 +54,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         for (int budget = 0; budget < args.advance_budget; ++budget) {
             if (!__any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
-            if (state == ST_FETCH) {
-                uint32_t item = atomicAdd(args.queue, 1u);
-                if (item >= P.total_items) {
-                    state = ST_DONE;
-                } else {
-                    const uint32_t tt = (uint32_t)(P.tile * P.tile);
-                    const uint32_t k = item / tt, within = item % tt;
-                    const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
-                    const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
-                    const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;
-                    const uint32_t in_x = (sub % per_row) * 8u + (l & 7u), in_y = (sub / per_row) * 8u + (l >> 3);
-                    const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
-                    if (x < W && row < H) {
-                        px = x;
-                        ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
-                        out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
-                        rng = (uint32_t)(px + ky * W) ^ P.seed32;       // :990
-                        accum = mk(0, 0, 0);
-                        sample = 0;
-                        state = ST_GEN;
-                    }
-                }
-            } else if (state == ST_GEN) {
-                if (sample >= spp) {
-                    // tone map + store :1003-1030
-                    float inv_spp = 1.0f / (float)spp;
-                    F3 col = accum * inv_spp;
-                    col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
-                    col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
-                    col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
-                    col = clamp01(col);
-                    const size_t o = (size_t)out_index * 3;
-                    args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
-                    args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
-                    args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
-                    if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
-                    flush_counters();
-                    state = ST_FETCH;
-                } else {
-                    float jx = ((float)sample + rand01(rng)) / (float)spp;          // :995-996
-                    float jy = ((float)sample + rand01(rng)) / (float)spp;
-                    float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
-                    float v = ((float)ky + jy) / (float)(H - 1);
-                    ro = cam_o;
-                    rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
-                    depth = 0;
-                    L = mk(0, 0, 0);
-                    thr = mk(1, 1, 1);
-                    if (COUNT) c[C_SAMPLES]++;
-                    start_ray(ST_TRAV_CLOSEST, ST_SHADE);      // depth 0: no roulette, max_depth >= 1 (host guarantees)
-                }
-            } else if (state == ST_BOUNCE) {
-                // top of the depth loop :727-744
-                bool go = depth < P.max_depth;
-                if (go && depth >= 5) {
-                    float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
-                    p = fminf(p, 0.95f);
-                    if (rand01(rng) > p) go = false;
-                    else thr = thr * (1.0f / p);
-                }
-                if (!go) end_sample();
-                else start_ray(ST_TRAV_CLOSEST, ST_SHADE);
-            } else if (state == ST_SHADE) {
-                // ---- finish scene_hit :516-551: triangle record from (slot, t, u, v), then the spheres ----
-                bool hit_any = false;
-                F3 hp = mk(0, 0, 0), hn = mk(0, 0, 0);
-                int mat_id = 0, tex_id = -1;
-                bool front = true;
-                if (hit_slot >= 0) {
-                    const float4* sh = S.tri_shade + (size_t)hit_slot * 3;
-                    const float4 a0 = sh[0], a1 = sh[1], a2 = sh[2];
-                    const float t = closest;
-                    hp = mk(ro.x + t * rd.x, ro.y + t * rd.y, ro.z + t * rd.z);
-                    const float wgt = 1.0f - hit_u - hit_v;                                          // :359-369
-                    F3 n = ((mk(a0.x, a0.y, a0.z) * wgt) + (mk(a0.w, a1.x, a1.y) * hit_u)) + (mk(a1.z, a1.w, a2.x) * hit_v);
-                    n = normalize(n);
-                    front = dot(rd, n) < 0.0f;
-                    hn = front ? n : (n * -1.0f);
-                    mat_id = __float_as_int(a2.y);
-                    tex_id = __float_as_int(a2.z);
-                    hit_any = true;
-                }
-                for (int i = 0; i < S.num_spheres; ++i) {
-                    if (COUNT) c[C_SPHERE_TESTS]++;
-                    const GPUSphere sph = S.spheres[i];
-                    float t_hit; F3 n_hit;
-                    if (hit_sphere(sph, ro, rd, closest, t_hit, n_hit)) {
-                        hit_any = true;
-                        closest = t_hit;
-                        hp = mk(ro.x + t_hit * rd.x, ro.y + t_hit * rd.y, ro.z + t_hit * rd.z);
-                        front = dot(rd, n_hit) < 0.0f;
-                        hn = front ? n_hit : (n_hit * -1.0f);
-                        mat_id = sph.material_id;
-                        tex_id = -1;
-                    }
-                }
-                if (!hit_any) {
-                    end_sample();                                                                     // :744-747
-                } else {
-                    if (COUNT) { c[C_SHADED_HITS]++; if (depth == 0) c[C_PRIMARY_HITS]++; }
-                    if (CHECKED && (unsigned)mat_id >= (unsigned)S.num_materials) { flags |= kFlagBadMaterial; mat_id = 0; }
-                    const float4* mp = S.materials + (size_t)mat_id * 3;
-                    const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-                    const int mtype = __float_as_int(m0.x);
-                    if (mtype == MAT_DIFFUSE_LIGHT) {                                                 // :754-758
-                        L = L + (thr * mk(m1.w, m2.x, m2.y));
-                        end_sample();
-                    } else {
-                        F3 albedo = mk(m1.x, m1.y, m1.z);                                             // :763-774
-                        if (tex_id >= 0 && S.tri_uv) {
-                            const float4* uvp = S.tri_uv + (size_t)hit_slot * 2;
-                            const float4 u0 = uvp[0], u1 = uvp[1];
-                            const float wgt = 1.0f - hit_u - hit_v;
-                            const float u_tex = wgt * u0.x + hit_u * u0.z + hit_v * u1.x;
-                            const float v_tex = wgt * u0.y + hit_u * u0.w + hit_v * u1.y;
-                            albedo = albedo * tex2d(S, tex_id, u_tex, v_tex, c[C_TEX_FETCHES]);
-                        }
-                        if (mtype == MAT_DIELECTRIC) {                                               // scatter_dielectric :621-661
-                            float eta = m2.w;
-                            if (eta <= 0.0f || !isfinite(eta)) eta = 1.5f;
-                            const float ratio = front ? (1.0f / eta) : eta;
-                            const F3 unit = normalize(rd);
-                            const float cos_t = fminf(dot(unit * -1.0f, hn), 1.0f);
-                            const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
-                            const bool cannot = ratio * sin_t > 1.0f;
-                            const float rprob = schlick(cos_t, ratio);
-                            F3 dir;
-                            if (cannot || rprob > rand01(rng)) dir = reflect(unit, hn);
-                            else dir = refract(unit, hn, ratio);
-                            ro = hp; rd = dir;                      // attenuation is (1,1,1): throughput unchanged
-                            depth++;
-                            state = ST_BOUNCE;
-                        } else if (mtype == MAT_METAL) {                                             // scatter_metal :603-619
-                            const F3 refl = reflect(normalize(rd), hn);
-                            const float fuzz = fmaxf(0.0f, fminf(1.0f, m2.z));
-                            const F3 dir = refl + (random_in_unit_sphere(rng) * fuzz);
-                            if (dot(dir, hn) > 0.0f) {
-                                thr = thr * albedo;
-                                ro = hp; rd = dir;
-                                depth++;
-                                state = ST_BOUNCE;
-                            } else {
-                                end_sample();
-                            }
-                        } else {
-                            // ---- Lambertian: sun next-event estimation :800-836 ----
-                            bool need_shadow = false;
-                            F3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0);
-                            if (P.sun_enabled) {
-                                const F3 Ldir = normalize(mk(-P.sun_dir[0], -P.sun_dir[1], -P.sun_dir[2]));
-                                const float cos_t = fmaxf(0.0f, dot(hn, Ldir));
-                                if (cos_t > 0.0f) {
-                                    sh_o = hp + (hn * 1e-3f);
-                                    sh_d = Ldir;
-                                    const float pdf_brdf = cos_t / kPi;
-                                    const float pdf_mix = 0.5f * 1.0f + 0.5f * pdf_brdf;
-                                    const float weight = (cos_t / kPi) / pdf_mix;
-                                    pend_contrib = thr * (albedo * (ld3(P.sun_radiance) * weight));
-                                    need_shadow = true;
-                                }
-                            }
-                            // ---- next direction.  The shadow ray draws no random numbers, so sampling the bounce
-                            //      before tracing it leaves the LCG stream exactly as the reference's order does. ----
-                            bool end_after = false;
-                            F3 ndir = mk(0, 0, 1), nthr = thr;
-                            if (S.num_lights == 0) {                                                 // :852-866
-                                float pdf;
-                                ndir = sample_cosine_hemisphere(hn, rng, pdf);
-                                if (pdf <= 0.0f) end_after = true;
-                                else {
-                                    const float cos_t = fmaxf(0.0f, dot(ndir, hn));
-                                    const float spdf = cos_t / kPi;
-                                    nthr = thr * (albedo * (spdf / pdf));
-                                }
-                            } else {                                                                 // :871-932
-                                float pdf_val = 0.0f;
-                                const float choose = rand01(rng);
-                                if (choose < 0.5f) {
-                                    int k = (int)(rand01(rng) * (float)S.num_lights);
-                                    if (k >= S.num_lights) k = S.num_lights - 1;
-                                    int found = 0, light_idx = 0;
-                                    for (int i = 0; i < S.num_spheres; ++i) {
-                                        const float4* lm = S.materials + (size_t)S.spheres[i].material_id * 3;
-                                        const float4 l0 = lm[0], l1 = lm[1], l2 = lm[2];
-                                        if (__float_as_int(l0.x) == MAT_DIFFUSE_LIGHT && (l1.w > 0 || l2.x > 0 || l2.y > 0)) {
-                                            if (found == k) { light_idx = i; break; }
-                                            found++;
-                                        }
-                                    }
-                                    float pdf_lc = 0.0f;
-                                    sample_sphere_light(S.spheres[light_idx], hp, rng, ndir, pdf_lc);
-                                    if (pdf_lc <= 0.0f) end_after = true;
-                                    else {
-                                        const float cos_t = fmaxf(0.0f, dot(ndir, hn));
-                                        if (cos_t <= 0.0f) end_after = true;
-                                        else {
-                                            const float pdf_light = pdf_lc / (float)S.num_lights;
-                                            const float pdf_brdf = cos_t / kPi;
-                                            pdf_val = 0.5f * pdf_light + 0.5f * pdf_brdf;
-                                        }
-                                    }
-                                } else {
-                                    float pdf_brdf = 0.0f;
-                                    ndir = sample_cosine_hemisphere(hn, rng, pdf_brdf);
-                                    if (pdf_brdf <= 0.0f) end_after = true;
-                                    else pdf_val = 0.5f * pdf_brdf;
-                                }
-                                if (!end_after) {
-                                    const float cos_t = fmaxf(0.0f, dot(ndir, hn));
-                                    const float spdf = cos_t / kPi;
-                                    nthr = thr * (albedo * (spdf / pdf_val));
-                                }
-                            }
-                            if (need_shadow) {
-                                pend_end = end_after; pend_thr = nthr; pend_o = hp; pend_d = ndir;
-                                ro = sh_o; rd = sh_d;
-                                start_ray(ST_TRAV_SHADOW, ST_SHADOW_DONE);
-                            } else if (end_after) {
-                                end_sample();
-                            } else {
-                                thr = nthr; ro = hp; rd = ndir;
-                                depth++;
-                                state = ST_BOUNCE;
-                            }
-                        }
-                    }
-                }
-            } else if (state == ST_SHADOW_DONE) {
-                // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
-                bool blocked = hit_slot >= 0;
-                if (!blocked || !ANYHIT) {
-                    for (int i = 0; i < S.num_spheres; ++i) {
-                        if (COUNT) c[C_SPHERE_TESTS]++;
-                        float t_hit; F3 n_hit;
-                        if (hit_sphere(S.spheres[i], ro, rd, closest, t_hit, n_hit)) { blocked = true; closest = t_hit; }
-                    }
-                } else if (COUNT) {
-                    c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
-                }
-                if (!blocked) L = L + pend_contrib;
-                if (pend_end) end_sample();
-                else { thr = pend_thr; ro = pend_o; rd = pend_d; depth++; state = ST_BOUNCE; }
-            }
+            if (state < ST_TRAV_CLOSEST) advance_step<COUNT, CHECKED, ANYHIT>(ln, args, c, flags);
         }
 
         if (__all(state == ST_DONE)) break;
@@ -638,7 +189,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         }
     }
 
-    flush_counters();
+    flush_counters<COUNT>(args, c);
     if (flags) atomicOr(args.flags, flags);
 }
 

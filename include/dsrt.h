@@ -135,6 +135,8 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
+    int      variant;               /* kernel organisation: 0 = default, 1 = one lane per pixel (render_kernel.hip),
+                                       2 = workgroup-local wavefront (render_wavefront.hip).  Same output either way. */
     int      tune[3];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4} (see device_layout.h) */
 } DsrtRenderDesc;
 
