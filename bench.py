@@ -100,6 +100,7 @@ def main():
     import torch.distributed as dist
     import dsrt_amd as d
     from dsrt_amd import meshgen
+    from dsrt_amd import dist as shard_mod
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,8 +147,6 @@ def main():
     desc = d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard, stack_entries=args.stack_entries)
     lay = d.shard_layout(desc)
     part = torch.zeros(lay["rgb8_bytes_padded"] if shard else W * H * 3, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(part) for _ in range(world)] if (shard and rank == 0) else None
-    gathered_flat = torch.zeros(world * part.numel(), dtype=torch.uint8, device=dev) if (shard and rank == 0) else None
     image = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev) if shard and rank == 0 else part
 
     kernel_ms = []
@@ -157,10 +156,9 @@ def main():
         if collect:
             kernel_ms.append(st.kernel_ms)
         if shard:
-            dist.gather(part, gathered, dst=0)
+            flat = shard_mod.gather_to_root(part, world, rank)          # the one collective of the step (RCCL gather)
             if rank == 0:
-                torch.cat(gathered, out=gathered_flat)
-                ctx.deinterleave(desc, gathered_flat.data_ptr(), image.data_ptr(), stream=stream)
+                ctx.deinterleave(desc, flat.data_ptr(), image.data_ptr(), stream=stream)
 
     def timed(steps, warmup):
         kernel_ms.clear()

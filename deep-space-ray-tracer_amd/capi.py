@@ -81,14 +81,14 @@ class DsrtRenderDesc(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int), ("gamma", C.c_float),
                 ("seed", C.c_uint64), ("rng_mode", C.c_int), ("tile_size", C.c_int), ("shard_rank", C.c_int),
                 ("shard_count", C.c_int), ("collect_counters", C.c_int), ("checked", C.c_int), ("stack_entries", C.c_int),
-                ("variant", C.c_int), ("tune", C.c_int * 3)]
+                ("tune", C.c_int * 3)]
 
 
 class DsrtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("waves_launched", C.c_int), ("device_flags", C.c_uint32), ("lds_stack_entries", C.c_int)] + \
                [(n, C.c_uint64) for n in ("samples", "rays", "primary_hits", "box_fetches", "nodes_entered", "internal_entered", "tri_tests",
                                           "hit_updates", "sphere_tests", "shaded_hits", "tex_fetches", "stack_spills", "max_stack",
-                                          "node_slots", "tri_slots", "adv_slots", "adv_active")]
+                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done")]
 
 
 # numpy record layouts of the reference arrays (for dumping / comparing with goldens)

@@ -25,9 +25,6 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
-hipError_t launch_wavefront(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
-int wavefront_slots_per_block();
-size_t wavefront_state_words();
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -220,7 +217,6 @@ struct DsrtContext {
     PackedScene scene;
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
-    DevBuf<uint32_t> wf_state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 };
@@ -386,19 +382,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     if (K != 8 && K != 12 && K != 16 && K != 24) { set_error("dsrt_render: stack_entries must be 8, 12, 16 or 24"); return DSRT_ERR_INVALID; }
     if (desc->stack_entries <= 0 && sc.view.stack_need <= 8) K = 8;
 
-    const int variant = desc->variant == 0 ? 1 : desc->variant;
-    if (variant != 1 && variant != 2) { set_error("dsrt_render: unknown kernel variant"); return DSRT_ERR_INVALID; }
-    const int threads_per_block = variant == 2 ? 256 : 64 * kernel_waves_per_block();
-    int blocks;
-    if (variant == 2) {
-        blocks = ctx->num_cus * 4;
-        const long long needed = ((long long)f.total_items + wavefront_slots_per_block() - 1) / wavefront_slots_per_block();
-        if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
-        const size_t words = (size_t)blocks * wavefront_state_words();
-        if (ctx->wf_state.n < words) { int rc = ctx->wf_state.alloc(words); if (rc) return rc; }
-        a.wf_state = ctx->wf_state.p;
-    } else {
-        blocks = ctx->num_cus * 8;
+    const int threads_per_block = 64 * kernel_waves_per_block();
+    int blocks = ctx->num_cus * 8;
+    {
         const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
         if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
     }
@@ -418,8 +404,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    if (variant == 2) HIP_TRY(launch_wavefront(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
-    else HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -438,6 +423,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->shaded_hits = cnt[C_SHADED_HITS]; stats->tex_fetches = cnt[C_TEX_FETCHES]; stats->stack_spills = cnt[C_STACK_SPILLS];
         stats->max_stack = cnt[C_MAX_STACK];
         stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
+        stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
         if (stats->device_flags) {
             char buf[96];
             std::snprintf(buf, sizeof buf, "render kernel raised status flags 0x%x", stats->device_flags);

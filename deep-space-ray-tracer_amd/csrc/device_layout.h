@@ -84,14 +84,14 @@ struct RenderArgs {
     int       spill_entries;
     int       min_walk_iters;  // a traverse phase runs at least this many steps before it may yield to waiting lanes
     int       advance_budget;  // state transitions per lane per advance phase
-    uint32_t* wf_state;        // wavefront kernel: per-workgroup strips of pixel-slot state
     int       leaf_ratio4;     // phase I yields to the leaf phase when 4 * lanes_at_nodes < leaf_ratio4 * lanes_at_leaves
 };
 
 // order matches the DsrtStats tail in include/dsrt.h
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
-               C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE, kNumCounters };
+               C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, kNumCounters };
 
 // status bits raised by the checked build
 constexpr uint32_t kFlagBadNodeRef = 1u, kFlagBadTriSlot = 2u, kFlagBadMaterial = 4u, kFlagStackOverflow = 8u,

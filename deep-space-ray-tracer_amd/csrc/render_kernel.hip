@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                 const int n_leaf = __popcll(__ballot(walking && cur < 0));
                 if (n_node == 0 || 4 * n_node < args.leaf_ratio4 * n_leaf) break;
                 ++iter;
-                if (COUNT) c[C_NODE_SLOTS]++;
+                if (COUNT) { c[C_NODE_SLOTS]++; if (walking && cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
                 if (at_node) {
                     bool finished = false;
                     if (++steps > kStepCap) { flags |= kFlagStepCap; finished = true; }

@@ -135,8 +135,6 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
-    int      variant;               /* kernel organisation: 0 = default, 1 = one lane per pixel (render_kernel.hip),
-                                       2 = workgroup-local wavefront (render_wavefront.hip).  Same output either way. */
     int      tune[3];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4} (see device_layout.h) */
 } DsrtRenderDesc;
 
@@ -150,6 +148,8 @@ typedef struct DsrtStats {
     /* lane-slot accounting of the counting build: every lane of a wave adds 1 per wave iteration of the node loop / the
      * triangle loop / the advance loop, so active / slots is the SIMD utilisation of that loop */
     uint64_t node_slots, tri_slots, adv_slots, adv_active;
+    /* where the idle lanes of the node loop were: parked at a leaf / waiting for their state machine / out of work */
+    uint64_t idle_at_leaf, idle_waiting, idle_done;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of

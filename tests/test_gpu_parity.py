@@ -42,17 +42,13 @@ def test_device_math_is_bit_identical_to_host(dsrt, gpu_ctx, oracle):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), y
 
 
-VARIANTS = [1, 2]          # 1 = one lane per pixel (render_kernel.hip), 2 = workgroup-local wavefront (render_wavefront.hip)
-
-
-@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_render_matches_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, name, variant):
+def test_render_matches_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, name):
     hs, scene, W, H, spp, depth = _scene(dsrt, name)
     want_rgb, want_f32, want_cnt = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
     # counting build in reference-equivalent mode (no any-hit early-out): work counters must equal the oracle's exactly
-    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=2, variant=variant), want_f32=True)
+    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=2), want_f32=True)
     linf = float(np.abs(f32 - want_f32).max())
     assert linf <= LINF_TOLERANCE
     assert np.array_equal(rgb, want_rgb), f"{(rgb != want_rgb).any(axis=2).sum()} pixels differ, Linf={linf}"
@@ -61,19 +57,18 @@ def test_render_matches_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, name, variant)
                 "sphere_tests", "shaded_hits", "tex_fetches", "max_stack"):
         assert getattr(st, key) == want_cnt[key], (key, getattr(st, key), want_cnt[key])
     # production build (unchecked, any-hit shadow rays): same bytes, never more work
-    rgb2, f32b, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, variant=variant), want_f32=True)
+    rgb2, f32b, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth), want_f32=True)
     assert np.array_equal(rgb2, want_rgb) and np.array_equal(f32b.view(np.uint32), want_f32.view(np.uint32))
-    _, _, st1 = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=1, variant=variant))
+    _, _, st1 = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=1))
     assert st1.rays == want_cnt["rays"] and st1.tri_tests <= want_cnt["tri_tests"] and st1.nodes_entered <= want_cnt["nodes_entered"]
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("entries", [8, 12, 16, 24])
-def test_short_stack_sizes_and_spill_give_identical_images(dsrt, gpu_ctx, oracle, entries, variant):
+def test_short_stack_sizes_and_spill_give_identical_images(dsrt, gpu_ctx, oracle, entries):
     hs, scene, W, H, spp, depth = _scene(dsrt, "station_near")
     want_rgb, _, want_cnt = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    rgb, _, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=1, stack_entries=entries, variant=variant))
+    rgb, _, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=1, stack_entries=entries))
     assert np.array_equal(rgb, want_rgb)
     assert st.lds_stack_entries == entries and st.max_stack == want_cnt["max_stack"]
     if want_cnt["max_stack"] > entries:
@@ -82,8 +77,7 @@ def test_short_stack_sizes_and_spill_give_identical_images(dsrt, gpu_ctx, oracle
         assert st.stack_spills == 0
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_pose_frame_config_c2_shape(dsrt, gpu_ctx, oracle, tmp_path, variant):
+def test_pose_frame_config_c2_shape(dsrt, gpu_ctx, oracle, tmp_path):
     # BASELINE.json configs[1] in miniature: frame 0 of the pose file, 640x360; 20k-triangle stand-in mesh, 8 spp to keep the
     # oracle to a few seconds.  Frame 0 is almost all background; frame 98 fills the view.
     from dsrt_amd import meshgen
@@ -103,13 +97,12 @@ def test_pose_frame_config_c2_shape(dsrt, gpu_ctx, oracle, tmp_path, variant):
         else:
             gpu_ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))       # scene stays resident; only camera + sun change
         want_rgb, want_f32, cnt = oracle.render(scene, W, H)
-        rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, variant=variant), want_f32=True)
+        rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50), want_f32=True)
         assert cnt["primary_hits"] > 0
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), idx
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_tile_shards_reassemble_to_the_full_image(dsrt, gpu_ctx, oracle, variant):
+def test_tile_shards_reassemble_to_the_full_image(dsrt, gpu_ctx, oracle):
     import torch
     hs, scene, W, H, spp, depth = _scene(dsrt, "station_near")
     want_rgb, _, _ = oracle.render(scene, W, H)
@@ -118,7 +111,7 @@ def test_tile_shards_reassemble_to_the_full_image(dsrt, gpu_ctx, oracle, variant
         lay = dsrt.shard_layout(dsrt.make_desc(W, H, spp, depth, tile_size=tile, shard_count=world))
         gathered = torch.zeros(world * lay["rgb8_bytes_padded"], dtype=torch.uint8, device="cuda")
         for rank in range(world):
-            d = dsrt.make_desc(W, H, spp, depth, tile_size=tile, shard_rank=rank, shard_count=world, variant=variant)
+            d = dsrt.make_desc(W, H, spp, depth, tile_size=tile, shard_rank=rank, shard_count=world)
             part = gathered[rank * lay["rgb8_bytes_padded"]:(rank + 1) * lay["rgb8_bytes_padded"]]
             gpu_ctx.render(d, part.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         image = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
@@ -126,10 +119,12 @@ def test_tile_shards_reassemble_to_the_full_image(dsrt, gpu_ctx, oracle, variant
                              stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), want_rgb), (world, tile)
+        # the host-side mirror of the layout (used by the gloo tests and for debugging) agrees with the kernels
+        from dsrt_amd import dist as shard
+        assert np.array_equal(shard.deinterleave_host(gathered.cpu().numpy(), W, H, world, tile), want_rgb)
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-def test_ragged_image_sizes(dsrt, gpu_ctx, oracle, variant):
+def test_ragged_image_sizes(dsrt, gpu_ctx, oracle):
     # width/height not multiples of the 8x8 work item: edge items are clipped, nothing is written out of bounds
     hs = load_world(dsrt, "lights")
     gpu_ctx_uploaded = False
@@ -142,7 +137,7 @@ def test_ragged_image_sizes(dsrt, gpu_ctx, oracle, variant):
         else:
             gpu_ctx.set_camera_sun(cam, SUN)
         want_rgb, _, _ = oracle.render(scene, W, H)
-        rgb, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 4, 12, checked=1, variant=variant))
+        rgb, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 4, 12, checked=1))
         assert np.array_equal(rgb, want_rgb), (W, H)
 
 

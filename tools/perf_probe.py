@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--stack", type=str, default="0")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--counters", action="store_true")
-    ap.add_argument("--variant", type=str, default="0")
     ap.add_argument("--tune", type=str, default="0:0:0", help="comma list of min_walk:adv_budget:leaf_ratio4")
     a = ap.parse_args()
     import dsrt_amd as d
@@ -41,20 +40,21 @@ def main():
             up = True
         else:
             ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
-        for variant, K, tune in [(int(vv), int(x), tuple(int(v) for v in t.split(":"))) for vv in a.variant.split(",") for x in a.stack.split(",") for t in a.tune.split(",")]:
+        for K, tune in [(int(x), tuple(int(v) for v in t.split(":"))) for x in a.stack.split(",") for t in a.tune.split(",")]:
             best = None
             for _ in range(a.reps):
-                _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, tune=tune, variant=variant))
+                _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, tune=tune))
                 best = st.kernel_ms if best is None else min(best, st.kernel_ms)
             rec = {"frame": fi, "sep_m": round(fr.sep_m, 1), "tris": hs.view().num_triangles, "WxHxspp": f"{W}x{H}x{spp}", "K": st.lds_stack_entries,
-                   "variant": variant, "tune": tune, "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
+                   "tune": tune, "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
             if a.counters:
-                _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1, tune=tune, variant=variant))
+                _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1, tune=tune))
                 rec.update({"coverage": round(sc.primary_hits / sc.samples, 4), "rays_per_sample": round(sc.rays / sc.samples, 3),
                             "Mrays_s": round(sc.rays / best / 1e3, 1), "nodes_per_ray": round(sc.nodes_entered / max(1, sc.rays), 2),
                             "tris_per_ray": round(sc.tri_tests / max(1, sc.rays), 2), "max_stack": sc.max_stack, "spills": sc.stack_spills,
                             "util_node": round(sc.internal_entered / max(1, sc.node_slots), 3), "util_tri": round(sc.tri_tests / max(1, sc.tri_slots), 3),
                             "util_adv": round(sc.adv_active / max(1, sc.adv_slots), 3),
+                            "node_idle_leaf_wait_done": [round(sc.idle_at_leaf / max(1, sc.node_slots), 3), round(sc.idle_waiting / max(1, sc.node_slots), 3), round(sc.idle_done / max(1, sc.node_slots), 3)],
                             "wave_iters_node_tri_adv": [sc.node_slots // 64, sc.tri_slots // 64, sc.adv_slots // 64]})
             print(json.dumps(rec), flush=True)
 
