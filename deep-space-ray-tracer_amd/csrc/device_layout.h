@@ -32,6 +32,7 @@ namespace dsrt {
 
 constexpr int kLeafBit = (int)0x80000000u;
 constexpr int kRefNone = 0x7FFFFFFF;           // "no node": traversal finished / no BVH
+constexpr int kRefPop = 0x7FFFFFFE;            // "take the next postponed child from the stack"
 
 __host__ __device__ inline bool ref_is_leaf(int r) { return r < 0; }
 __host__ __device__ inline int leaf_code(int r) { return (r >> 28) & 7; }

@@ -32,7 +32,7 @@ constexpr int kWavesPerBlock = 4;
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const RenderArgs args) {
     const DeviceScene& S = args.scene;
-    __shared__ uint2 lds_stack[kWavesPerBlock][K][64];
+    __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -60,31 +60,48 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         if (__all(state == ST_DONE)) break;
 
         // =====================================================================================
-        // TRAVERSE phase ("while-while"): lanes at internal nodes step together; lanes that reached a leaf WAIT there
-        // until at least as many lanes are parked at leaves as are still descending, then all parked leaves are
-        // intersected together, one triangle index at a time, fully predicated.  Each lane still performs exactly the
-        // reference's sequence of box tests, triangle tests and pops -- only WHEN a lane runs changes, never what it does.
+        // TRAVERSE phase ("while-while"), written flat: per wave iteration every lane that is descending performs at most
+        // one POP ATTEMPT and one NODE VISIT, both as straight predicated code (no inner loops, no nested branches); lanes
+        // that reached a leaf PARK there until enough lanes are parked, then all parked leaves are intersected together,
+        // one triangle index at a time.  Each lane still performs exactly the reference's sequence of box tests,
+        // triangle tests and pops -- only WHEN a lane runs changes, never what it does.
+        //   cur >= 0 (< kRefPop): internal node to visit   cur == kRefPop: take the next postponed child
+        //   cur <  0            : parked at a leaf          cur == kRefNone: no ray
         // =====================================================================================
         for (int iter = 0;;) {
-            const bool walking = (state == ST_TRAV_CLOSEST) || (state == ST_TRAV_SHADOW);
+            const bool walking = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
             const int n_walk = __popcll(__ballot(walking));
             if (n_walk == 0) break;
             const int n_wait = __popcll(__ballot(state < ST_TRAV_CLOSEST));
             if (iter >= args.min_walk_iters && n_walk < n_wait) break;
 
-            // ---------------- phase I: internal nodes ----------------
+            // ---------------- phase I: pops and internal nodes ----------------
             for (;;) {
-                const bool at_node = walking && cur >= 0 && cur != kRefNone;
-                const int n_node = __popcll(__ballot(at_node));
-                const int n_leaf = __popcll(__ballot(walking && cur < 0));
-                if (n_node == 0 || 4 * n_node < args.leaf_ratio4 * n_leaf) break;
+                const bool live = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
+                const int n_desc = __popcll(__ballot(live && cur >= 0));
+                const int n_leaf = __popcll(__ballot(live && cur < 0));
+                if (n_desc == 0 || 4 * n_desc < args.leaf_ratio4 * n_leaf) break;
                 ++iter;
-                if (COUNT) { c[C_NODE_SLOTS]++; if (walking && cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
-                if (at_node) {
-                    bool finished = false;
-                    if (++steps > kStepCap) { flags |= kFlagStepCap; finished = true; }
-                    else if (CHECKED && (unsigned)cur >= (unsigned)S.num_pairs) { flags |= kFlagBadNodeRef; finished = true; }
+                if (COUNT) { c[C_NODE_SLOTS]++; if (live && cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
+
+                // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
+                // bbox_hit(node, ray, t_min, closest) for a box already known to be hit (src/gpu_render.cu:422-424, 462-468)
+                if (live && cur == kRefPop) {
+                    if (sp == 0) { cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE); }
                     else {
+                        --sp;
+                        uint2 e = lds_stack[wave][sp < K ? sp : K][lane];
+                        if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
+                        if (closest > __uint_as_float(e.y)) cur = (int)e.x;
+                    }
+                }
+
+                // node visit: both child boxes from one 64-byte record
+                if (live && (unsigned)cur < (unsigned)kRefPop) {
+                    if (CHECKED && (cur >= S.num_pairs || ++steps > kStepCap)) {
+                        flags |= cur >= S.num_pairs ? kFlagBadNodeRef : kFlagStepCap;
+                        cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE);
+                    } else {
                         const float4* rec = S.pairs + (size_t)cur * 4;
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                         const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
@@ -94,46 +111,34 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         float tl, tr;
                         const bool hl = slab(l_lo, l_hi, ro, rinv, closest, tl);
                         const bool hr = slab(r_lo, r_hi, ro, rinv, closest, tr);
-                        // nearer child by box centre along the ray :433-453 (only decides anything when both are hit)
+                        // nearer child by box centre along the ray :433-453 (only matters when both are hit)
                         const F3 cl = mk(0.5f * (l_lo.x + l_hi.x), 0.5f * (l_lo.y + l_hi.y), 0.5f * (l_lo.z + l_hi.z));
                         const F3 cr = mk(0.5f * (r_lo.x + r_hi.x), 0.5f * (r_lo.y + r_hi.y), 0.5f * (r_lo.z + r_hi.z));
                         const float dl = dot(cl - ro, rd), dr = dot(cr - ro, rd);
                         const bool left_near = dl < dr;
-                        if (hl && hr) {
-                            const int far_ref = left_near ? ref_r : ref_l;
-                            const float far_t = left_near ? tr : tl;
-                            cur = left_near ? ref_l : ref_r;
-                            const uint2 e = make_uint2((uint32_t)far_ref, __float_as_uint(far_t));
-                            if (sp < K) lds_stack[wave][sp][lane] = e;
-                            else if (sp - K < args.spill_entries) { args.spill[(size_t)(sp - K) * args.spill_stride + glane] = e; if (COUNT) c[C_STACK_SPILLS]++; }
-                            else { flags |= kFlagStackOverflow; finished = true; }
-                            sp++;
-                            if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
-                        } else if (hl) cur = ref_l;
-                        else if (hr) cur = ref_r;
-                        else {
-                            // pop: a postponed child is entered iff its entry distance is still in front of `closest`,
-                            // which is bbox_hit(node, ray, t_min, closest) for a box already known to be hit
-                            cur = kRefNone;
-                            for (;;) {
-                                if (sp == 0) { finished = true; break; }
-                                sp--;
-                                uint2 e = lds_stack[wave][sp < K ? sp : K - 1][lane];
-                                if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
-                                if (closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
-                            }
+                        const bool both = hl && hr;
+                        // the far child goes to stack[sp]; written unconditionally (slot sp is above the top, slot K is a dump
+                        // slot for sp >= K), the stack only grows when both children were hit
+                        lds_stack[wave][sp < K ? sp : K][lane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
+                        if (both && sp >= K) {
+                            if (sp - K < args.spill_entries) {
+                                args.spill[(size_t)(sp - K) * args.spill_stride + glane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
+                                if (COUNT) c[C_STACK_SPILLS]++;
+                            } else flags |= kFlagStackOverflow;
                         }
+                        sp += both ? 1 : 0;
+                        if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
+                        const int near_ref = left_near ? ref_l : ref_r;
+                        cur = both ? near_ref : (hl ? ref_l : (hr ? ref_r : kRefPop));
                     }
-                    if (finished) { cur = kRefNone; state = (state == ST_TRAV_CLOSEST) ? ST_SHADE : ST_SHADOW_DONE; }
                 }
             }
 
             // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
-            const bool at_leaf = ((state == ST_TRAV_CLOSEST) || (state == ST_TRAV_SHADOW)) && cur < 0;
+            const bool at_leaf = ((unsigned)(state - ST_TRAV_CLOSEST) <= 1u) && cur < 0;
             if (__any(at_leaf)) {
                 ++iter;
                 int first = 0, count = 0;
-                bool finished = false;
                 if (at_leaf) {
                     first = leaf_payload(cur);
                     count = leaf_code(cur) + 1;
@@ -141,9 +146,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         if (CHECKED && first >= S.num_big_leaves) { flags |= kFlagBadBigLeaf; first = 0; count = 0; }
                         else { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
                     }
-                    if (CHECKED && (first < 0 || first + count > S.num_tris)) { flags |= kFlagBadTriSlot; count = 0; }
-                    if (++steps > kStepCap) { flags |= kFlagStepCap; count = 0; finished = true; }
+                    if (CHECKED && (first < 0 || first + count > S.num_tris || ++steps > kStepCap)) { flags |= kFlagBadTriSlot; count = 0; }
                     if (COUNT) c[C_NODES_ENTERED]++;
+                    cur = kRefPop;
                 }
                 for (int i = 0; __any(i < count); ++i) {
                     if (COUNT) c[C_TRI_SLOTS]++;
@@ -168,22 +173,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         if (accept) {
                             closest = t; hit_slot = slot; hit_u = u; hit_v = v;
                             if (COUNT) c[C_HIT_UPDATES]++;
-                            if (ANYHIT && state == ST_TRAV_SHADOW) { finished = true; count = 0; }
+                            if (ANYHIT && state == ST_TRAV_SHADOW) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
                         }
                     }
-                }
-                if (at_leaf) {
-                    cur = kRefNone;
-                    if (!finished) {
-                        for (;;) {
-                            if (sp == 0) { finished = true; break; }
-                            sp--;
-                            uint2 e = lds_stack[wave][sp < K ? sp : K - 1][lane];
-                                if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
-                            if (closest > __uint_as_float(e.y)) { cur = (int)e.x; break; }
-                        }
-                    }
-                    if (finished) { cur = kRefNone; state = (state == ST_TRAV_CLOSEST) ? ST_SHADE : ST_SHADOW_DONE; }
                 }
             }
         }
