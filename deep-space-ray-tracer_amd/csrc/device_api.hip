@@ -25,6 +25,7 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, hipStream_t stream);
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -217,6 +218,7 @@ struct DsrtContext {
     PackedScene scene;
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
+    DevBuf<uint32_t> tile_cost, tile_order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 };
@@ -401,6 +403,12 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 4;
 
+    // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off)
+    if (desc->tune[3] != 1 && t.mine > 0) {
+        if (ctx->tile_cost.n < (size_t)t.mine) { int rc = ctx->tile_cost.alloc((size_t)t.mine); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine); if (rc) return rc; }
+        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, stream));
+        a.frame.tile_order = ctx->tile_order.p;
+    }
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;

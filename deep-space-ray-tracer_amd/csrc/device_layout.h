@@ -70,6 +70,7 @@ struct FrameParams {
     int   local_tiles;         // tiles owned by this shard
     uint32_t total_items;      // local_tiles * tile * tile
     int   compact_output;      // 1: tile-major shard buffer, 0: image order
+    const uint32_t* tile_order; // processing order of this shard's tiles (local tile numbers, costliest first); null = natural order
 };
 
 struct RenderArgs {

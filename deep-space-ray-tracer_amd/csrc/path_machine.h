@@ -92,7 +92,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             state = ST_DONE;
         } else {
             const uint32_t tt = (uint32_t)(P.tile * P.tile);
-            const uint32_t k = item / tt, within = item % tt;
+            const uint32_t within = item % tt;
+            const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
             const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
             const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;

@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                     else {
                         --sp;
                         uint2 e = lds_stack[wave][sp < K ? sp : K][lane];
-                        if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
+                        if (__any(sp >= K)) {               // wave-uniform guard: keeps the common path a plain ds_read_b64
+                            if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
+                        }
                         if (closest > __uint_as_float(e.y)) cur = (int)e.x;
                     }
                 }
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         // the far child goes to stack[sp]; written unconditionally (slot sp is above the top, slot K is a dump
                         // slot for sp >= K), the stack only grows when both children were hit
                         lds_stack[wave][sp < K ? sp : K][lane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
-                        if (both && sp >= K) {
+                        if (__any(both && sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store
                             if (sp - K < args.spill_entries) {
                                 args.spill[(size_t)(sp - K) * args.spill_stride + glane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
                                 if (COUNT) c[C_STACK_SPILLS]++;
@@ -183,6 +185,96 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
 
     flush_counters<COUNT>(args, c);
     if (flags) atomicOr(args.flags, flags);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Scheduling pre-pass: how expensive is each screen tile?  One wave per 8x8 pixel block traces the un-jittered centre
+// ray of every pixel with an any-hit walk; the tile's cost is the number of pixels that see geometry.  The render
+// kernel then hands tiles out costliest first, so the pixels that are 1000-sample serial chains start early and the
+// end of the frame is filled with background pixels instead of a long tail.  This changes only the ORDER in which
+// pixels are rendered, never a pixel's value (each pixel depends on nothing but its own coordinates and the scene).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S, const FrameParams P, uint32_t* __restrict__ cost) {
+    const uint32_t blocks_per_tile = (uint32_t)((P.tile >> 3) * (P.tile >> 3));
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (wave_id >= (uint32_t)P.local_tiles * blocks_per_tile) return;
+    const uint32_t k = wave_id / blocks_per_tile, sub = wave_id % blocks_per_tile, per_row = (uint32_t)P.tile >> 3;
+    const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
+    const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
+    const int x = (int)(tx * (uint32_t)P.tile + (sub % per_row) * 8u + (lane & 7u));
+    const int row = (int)(ty * (uint32_t)P.tile + (sub / per_row) * 8u + (lane >> 3));
+    bool hit = false;
+    if (x < P.width && row < P.height) {
+        const int ky = P.height - 1 - row;
+        const float u = ((float)x + 0.5f) / (float)(P.width - 1), v = ((float)ky + 0.5f) / (float)(P.height - 1);
+        const F3 ro = ld3(P.cam_origin);
+        const F3 rd = ((ld3(P.cam_llc) + (ld3(P.cam_horizontal) * u)) + (ld3(P.cam_vertical) * v)) - ro;
+        const F3 rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        for (int i = 0; i < S.num_spheres && !hit; ++i) { float t; F3 n; hit = hit_sphere(S.spheres[i], ro, rd, kTMax, t, n); }
+        float t_entry;
+        if (!hit && S.root_ref != kRefNone && slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, kTMax, t_entry)) {
+            int stack[64];
+            int sp = 0, cur = S.root_ref;
+            for (int guard = 0; guard < (1 << 20) && !hit; ++guard) {
+                if (cur >= 0) {
+                    const float4* rec = S.pairs + (size_t)cur * 4;
+                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                    float tl, tr;
+                    const bool hl = slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ro, rinv, kTMax, tl);
+                    const bool hr = slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ro, rinv, kTMax, tr);
+                    const int rl = __float_as_int(q3.x), rr = __float_as_int(q3.y);
+                    if (hl && hr) { if (sp < 64) stack[sp++] = rr; cur = rl; }
+                    else if (hl) cur = rl;
+                    else if (hr) cur = rr;
+                    else { if (sp == 0) break; cur = stack[--sp]; }
+                } else {
+                    int first = leaf_payload(cur), count = leaf_code(cur) + 1;
+                    if (count == 8) { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
+                    for (int i = 0; i < count && !hit; ++i) {
+                        const float4* tp = S.tri_isect + (size_t)(first + i) * 3;
+                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                        const F3 v0 = mk(a0.x, a0.y, a0.z), e1 = mk(a0.w, a1.x, a1.y), e2 = mk(a1.z, a1.w, a2.x);
+                        const F3 pvec = cross(rd, e2);
+                        const float det = dot(e1, pvec);
+                        const float inv_det = 1.0f / det;
+                        const F3 tvec = ro - v0;
+                        const float uu = dot(tvec, pvec) * inv_det;
+                        const F3 qvec = cross(tvec, e1);
+                        const float vv = dot(rd, qvec) * inv_det;
+                        const float t = dot(e2, qvec) * inv_det;
+                        hit = !(fabsf(det) < 1e-8f) && !(uu < 0.0f) && !(uu > 1.0f) && !(vv < 0.0f) && !(uu + vv > 1.0f) && !(t < kTMin) && !(t > kTMax);
+                    }
+                    if (sp == 0) break;
+                    cur = stack[--sp];
+                }
+            }
+        }
+    }
+    const uint32_t n = (uint32_t)__popcll(__ballot(hit));
+    if (lane == 0 && n) atomicAdd(&cost[k], n);
+}
+
+// One block: counting sort of the shard's tiles by cost, costliest first (65 bins; order inside a bin does not matter).
+__global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile) {
+    __shared__ uint32_t bins[65], cursor[65];
+    const uint32_t full = (uint32_t)(tile * tile);
+    for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&bins[64u - min(64u, cost[t] * 64u / full)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) order[atomicAdd(&cursor[64u - min(64u, cost[t] * 64u / full)], 1u)] = (uint32_t)t;
+}
+
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, hipStream_t stream) {
+    const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));
+    hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile);
+    return hipGetLastError();
 }
 
 // Tile-major shards -> image order, on the root after the gather.

@@ -135,7 +135,8 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
-    int      tune[3];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4} (see device_layout.h) */
+    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, 1 = natural tile
+                                       order instead of costliest-first} (see device_layout.h); none of them changes a pixel */
 } DsrtRenderDesc;
 
 typedef struct DsrtStats {
