@@ -399,9 +399,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.spill = ctx->spill.p;
     a.spill_stride = (uint32_t)lanes;
     a.spill_entries = spill_entries;
-    a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 16;
+    a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
-    a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 4;
+    a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 24;
 
     // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off)
     if (desc->tune[3] != 1 && t.mine > 0) {

@@ -84,9 +84,9 @@ struct RenderArgs {
     uint2*    spill;           // stack overflow area: [(entry - K) * spill_stride + global lane]
     uint32_t  spill_stride;
     int       spill_entries;
-    int       min_walk_iters;  // a traverse phase runs at least this many steps before it may yield to waiting lanes
+    int       min_walk_iters;  // x10: the traverse phase yields to ADVANCE once (waiting lane-slots wasted) >= this/10 * walking lanes
     int       advance_budget;  // state transitions per lane per advance phase
-    int       leaf_ratio4;     // phase I yields to the leaf phase when 4 * lanes_at_nodes < leaf_ratio4 * lanes_at_leaves
+    int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
 };
 
 // order matches the DsrtStats tail in include/dsrt.h

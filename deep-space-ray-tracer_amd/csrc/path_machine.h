@@ -28,10 +28,15 @@ struct Lane {
     int cur = kRefNone, sp = 0, hit_slot = -1;
     float closest = kTMax, hit_u = 0.0f, hit_v = 0.0f;
     uint32_t steps = 0;
-    // postponed continuation while the shadow ray is in flight
-    F3 pend_contrib = {0, 0, 0}, pend_thr = {0, 0, 0}, pend_o = {0, 0, 0}, pend_d = {0, 0, 0};
-    bool pend_end = false;
+    // The continuation postponed while a shadow ray is in flight (sun term, next throughput, next ray, "path ends") is
+    // 13 words that nothing touches during the walk: it lives in LDS, one column per lane, not in registers.
+    float* pend = nullptr;                      // &strip[0][lane of block], element i at pend[i * kPendStride]
 };
+
+constexpr int kPendStride = 256;                // = threads per block of the render kernel
+constexpr int kPendWords = 13;
+__device__ __forceinline__ void pend_put(const Lane& ln, int i, F3 v) { ln.pend[(i + 0) * kPendStride] = v.x; ln.pend[(i + 1) * kPendStride] = v.y; ln.pend[(i + 2) * kPendStride] = v.z; }
+__device__ __forceinline__ F3 pend_get(const Lane& ln, int i) { return mk(ln.pend[(i + 0) * kPendStride], ln.pend[(i + 1) * kPendStride], ln.pend[(i + 2) * kPendStride]); }
 
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RenderArgs& args, uint32_t* c) {
@@ -55,8 +60,6 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
     float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v;
     uint32_t& steps = ln.steps;
-    F3& pend_contrib = ln.pend_contrib; F3& pend_thr = ln.pend_thr; F3& pend_o = ln.pend_o; F3& pend_d = ln.pend_d;
-    bool& pend_end = ln.pend_end;
     const int spp = P.spp;
     const int W = P.width, H = P.height;
 
@@ -245,7 +248,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                             const float pdf_brdf = cos_t / kPi;
                             const float pdf_mix = 0.5f * 1.0f + 0.5f * pdf_brdf;
                             const float weight = (cos_t / kPi) / pdf_mix;
-                            pend_contrib = thr * (albedo * (ld3(P.sun_radiance) * weight));
+                            pend_put(ln, 0, thr * (albedo * (ld3(P.sun_radiance) * weight)));
                             need_shadow = true;
                         }
                     }
@@ -302,7 +305,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                         }
                     }
                     if (need_shadow) {
-                        pend_end = end_after; pend_thr = nthr; pend_o = hp; pend_d = ndir;
+                        ln.pend[12 * kPendStride] = end_after ? 1.0f : 0.0f; pend_put(ln, 3, nthr); pend_put(ln, 6, hp); pend_put(ln, 9, ndir);
                         ro = sh_o; rd = sh_d;
                         start_ray(ST_TRAV_SHADOW, ST_SHADOW_DONE);
                     } else if (end_after) {
@@ -327,9 +330,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         } else if (COUNT) {
             c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
         }
-        if (!blocked) L = L + pend_contrib;
-        if (pend_end) end_sample();
-        else { thr = pend_thr; ro = pend_o; rd = pend_d; depth++; state = ST_BOUNCE; }
+        if (!blocked) L = L + pend_get(ln, 0);
+        if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
+        else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
     }
 }
 

@@ -38,7 +38,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
     const int wave = threadIdx.x >> 6;
     const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
 
+    __shared__ float lds_pend[kPendWords][kPendStride];
+    static_assert(kPendStride == 64 * kWavesPerBlock, "pend strip is one column per thread of the block");
     Lane ln;
+    ln.pend = &lds_pend[0][threadIdx.x];
     int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
     float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v; uint32_t& steps = ln.steps;
     F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
@@ -68,20 +71,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         //   cur >= 0 (< kRefPop): internal node to visit   cur == kRefPop: take the next postponed child
         //   cur <  0            : parked at a leaf          cur == kRefNone: no ray
         // =====================================================================================
-        for (int iter = 0;;) {
+        // Leaving a phase is decided by accumulated waste, in lane-slots: every wave iteration spent here costs the lanes
+        // that are waiting for the OTHER phase one slot each; switching costs the lanes that are busy HERE one pass of the
+        // other phase.  Switch when the first exceeds the second (the ratios are the relative lengths of the phases' code).
+        for (int wait_waste = 0;;) {
             const bool walking = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
             const int n_walk = __popcll(__ballot(walking));
             if (n_walk == 0) break;
             const int n_wait = __popcll(__ballot(state < ST_TRAV_CLOSEST));
-            if (iter >= args.min_walk_iters && n_walk < n_wait) break;
+            if (wait_waste * 10 >= n_walk * args.min_walk_iters) break;
+            int leaf_waste = 0;
 
             // ---------------- phase I: pops and internal nodes ----------------
             for (;;) {
                 const bool live = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
                 const int n_desc = __popcll(__ballot(live && cur >= 0));
                 const int n_leaf = __popcll(__ballot(live && cur < 0));
-                if (n_desc == 0 || 4 * n_desc < args.leaf_ratio4 * n_leaf) break;
-                ++iter;
+                if (n_desc == 0 || leaf_waste * 10 >= n_desc * args.leaf_ratio4) break;
+                leaf_waste += n_leaf;
+                wait_waste += n_wait;
                 if (COUNT) { c[C_NODE_SLOTS]++; if (live && cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
             // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
             const bool at_leaf = ((unsigned)(state - ST_TRAV_CLOSEST) <= 1u) && cur < 0;
             if (__any(at_leaf)) {
-                ++iter;
+                wait_waste += n_wait;
                 int first = 0, count = 0;
                 if (at_leaf) {
                     first = leaf_payload(cur);
