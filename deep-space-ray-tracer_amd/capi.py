@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsrt_hip.so")
+LIB_PATH = os.environ.get("DSRT_LIB", os.path.join(_HERE, "libdsrt_hip.so"))
 
 
 class DsrtF3(C.Structure):
@@ -88,7 +88,7 @@ class DsrtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("waves_launched", C.c_int), ("device_flags", C.c_uint32), ("lds_stack_entries", C.c_int)] + \
                [(n, C.c_uint64) for n in ("samples", "rays", "primary_hits", "box_fetches", "nodes_entered", "internal_entered", "tri_tests",
                                           "hit_updates", "sphere_tests", "shaded_hits", "tex_fetches", "stack_spills", "max_stack",
-                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done")]
+                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12")]
 
 
 # numpy record layouts of the reference arrays (for dumping / comparing with goldens)

@@ -107,6 +107,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         std::vector<Item> todo{{0, 0}};
         int stack_need = 0;
         std::vector<int> order;                                          // internal nodes in visiting order
+        std::vector<int> depth_of;                                       // ... and their depth (root = 0)
         while (!todo.empty()) {
             Item it = todo.back(); todo.pop_back();
             if (it.node < 0 || it.node >= M) { set_error("BVH child index out of range"); return DSRT_ERR_INVALID; }
@@ -119,6 +120,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
             } else {
                 slot_of[it.node] = (int)order.size();
                 order.push_back(it.node);
+                depth_of.push_back(it.internal_above);
                 todo.push_back({n.right, it.internal_above + 1});
                 todo.push_back({n.left, it.internal_above + 1});
             }
@@ -136,10 +138,10 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
             const GPUBVHNode& n = h.bvh_nodes[order[s]];
             const GPUBVHNode& l = h.bvh_nodes[n.left];
             const GPUBVHNode& r = h.bvh_nodes[n.right];
-            pairs[4 * s + 0] = as_f4(l.bbox_min.x, l.bbox_min.y, l.bbox_min.z, l.bbox_max.x);
-            pairs[4 * s + 1] = as_f4(l.bbox_max.y, l.bbox_max.z, r.bbox_min.x, r.bbox_min.y);
-            pairs[4 * s + 2] = as_f4(r.bbox_min.z, r.bbox_max.x, r.bbox_max.y, r.bbox_max.z);
-            pairs[4 * s + 3] = as_f4(bits(ref_of(n.left)), bits(ref_of(n.right)), 0.0f, 0.0f);
+            pairs[4 * s + 0] = as_f4(l.bbox_min.x, r.bbox_min.x, l.bbox_max.x, r.bbox_max.x);
+            pairs[4 * s + 1] = as_f4(l.bbox_min.y, r.bbox_min.y, l.bbox_max.y, r.bbox_max.y);
+            pairs[4 * s + 2] = as_f4(l.bbox_min.z, r.bbox_min.z, l.bbox_max.z, r.bbox_max.z);
+            pairs[4 * s + 3] = as_f4(bits(ref_of(n.left)), bits(ref_of(n.right)), bits(depth_of[s]), 0.0f);
         }
         const GPUBVHNode& root = h.bvh_nodes[0];
         v.root_lo[0] = root.bbox_min.x; v.root_lo[1] = root.bbox_min.y; v.root_lo[2] = root.bbox_min.z;
@@ -379,13 +381,11 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.flags = ctx->ctrl.p + 1;
     a.counters = (uint64_t*)(ctx->ctrl.p + 4);
 
-    // LDS short-stack size: what the BVH can need, capped at the default; the rest spills.
-    int K = desc->stack_entries > 0 ? desc->stack_entries : 12;
-    if (K != 8 && K != 12 && K != 16 && K != 24) { set_error("dsrt_render: stack_entries must be 8, 12, 16 or 24"); return DSRT_ERR_INVALID; }
-    if (desc->stack_entries <= 0 && sc.view.stack_need <= 8) K = 8;
-
+    // LDS short-stack: 8 entries per lane (what fits beside the tree top and the continuation strip); deeper entries spill.
+    const int K = 8;
+    if (desc->stack_entries != 0 && desc->stack_entries != 8) { set_error("dsrt_render: stack_entries must be 0 or 8"); return DSRT_ERR_INVALID; }
     const int threads_per_block = 64 * kernel_waves_per_block();
-    int blocks = ctx->num_cus * 8;
+    int blocks = ctx->num_cus * 8;                                        // persistent; workgroups beyond the resident set find the queue empty
     {
         const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
         if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
@@ -432,6 +432,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->max_stack = cnt[C_MAX_STACK];
         stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
+        stats->visits_depth_lt6 = cnt[C_VISITS_LT6]; stats->visits_depth_lt9 = cnt[C_VISITS_LT9]; stats->visits_depth_lt12 = cnt[C_VISITS_LT12];
         if (stats->device_flags) {
             char buf[96];
             std::snprintf(buf, sizeof buf, "render kernel raised status flags 0x%x", stats->device_flags);

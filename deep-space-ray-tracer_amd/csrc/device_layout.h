@@ -5,10 +5,13 @@
 // three different 40-byte records (src/gpu_render.cu:408-431).  Here the scene is re-laid-out ONCE at upload
 // for how a wave64 traversal actually touches it:
 //
-//   pairs      one 64-byte record per INTERNAL node holding BOTH children's boxes and both child references:
-//              a node visit is one aligned 64-byte gather per lane (4 x dwordx4), not three scattered ones.
-//                q0 = (L.lo.x, L.lo.y, L.lo.z, L.hi.x)   q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
-//                q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)   q3 = (left_ref, right_ref, -, -) as int bits
+//   pairs      one 64-byte record per INTERNAL node holding BOTH children's boxes and both child references: a node
+//              visit is one aligned 64-byte gather per lane (4 x dwordx4), not three scattered ones.  The two boxes are
+//              interleaved so that every (left, right) pair of like coordinates sits in adjacent registers after the load
+//              and the slab arithmetic runs on packed fp32 instructions:
+//                q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x)   q1 = (L.lo.y, R.lo.y, L.hi.y, R.hi.y)
+//                q2 = (L.lo.z, R.lo.z, L.hi.z, R.hi.z)   q3 = (left_ref, right_ref, depth, -) as int bits
+//              Records are in depth-first order (a left child sits right behind its parent).
 //   child ref  >= 0: index of an internal node in `pairs`
 //              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles starting at slot
 //                    `payload` of the leaf-ordered triangle arrays; code 7: payload indexes `big_leaves` {first, count}
@@ -93,7 +96,7 @@ struct RenderArgs {
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
                C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
-               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, kNumCounters };
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, kNumCounters };
 
 // status bits raised by the checked build
 constexpr uint32_t kFlagBadNodeRef = 1u, kFlagBadTriSlot = 2u, kFlagBadMaterial = 4u, kFlagStackOverflow = 8u,

@@ -7,6 +7,8 @@
 
 namespace dsrt {
 
+typedef float v2f __attribute__((ext_vector_type(2)));     // a (left, right) pair: maps onto the packed fp32 VALU ops
+
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 mk(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ F3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }

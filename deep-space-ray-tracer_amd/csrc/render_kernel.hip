@@ -39,7 +39,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
     const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
 
     __shared__ float lds_pend[kPendWords][kPendStride];
-    static_assert(kPendStride == 64 * kWavesPerBlock, "pend strip is one column per thread of the block");
     Lane ln;
     ln.pend = &lds_pend[0][threadIdx.x];
     int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
@@ -115,17 +114,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         const float4* rec = S.pairs + (size_t)cur * 4;
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                         const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
-                        if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; }
-                        const F3 l_lo = mk(q0.x, q0.y, q0.z), l_hi = mk(q0.w, q1.x, q1.y);
-                        const F3 r_lo = mk(q1.z, q1.w, q2.x), r_hi = mk(q2.y, q2.z, q2.w);
-                        float tl, tr;
-                        const bool hl = slab(l_lo, l_hi, ro, rinv, closest, tl);
-                        const bool hr = slab(r_lo, r_hi, ro, rinv, closest, tr);
+                        if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; const int dpt = __float_as_int(q3.z); if (dpt < 6) c[C_VISITS_LT6]++; if (dpt < 9) c[C_VISITS_LT9]++; if (dpt < 12) c[C_VISITS_LT12]++; }
+                        // Both boxes at once: every quantity below is a (left, right) pair in two adjacent registers, so the
+                        // subtractions / multiplications are packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32: IEEE per component,
+                        // same results as the scalar forms).  Record layout: q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x), q1 = y, q2 = z.
+                        const v2f lox = {q0.x, q0.y}, hix = {q0.z, q0.w}, loy = {q1.x, q1.y}, hiy = {q1.z, q1.w}, loz = {q2.x, q2.y}, hiz = {q2.z, q2.w};
+                        const v2f ax = (lox - ro.x) * rinv.x, bx = (hix - ro.x) * rinv.x;      // bbox_hit :303-304
+                        const v2f ay = (loy - ro.y) * rinv.y, by = (hiy - ro.y) * rinv.y;
+                        const v2f az = (loz - ro.z) * rinv.z, bz = (hiz - ro.z) * rinv.z;
+                        const bool nx = rinv.x < 0.0f, ny = rinv.y < 0.0f, nz = rinv.z < 0.0f;       // the swap of :305-307
+                        const float t0xl = nx ? bx.x : ax.x, t1xl = nx ? ax.x : bx.x, t0xr = nx ? bx.y : ax.y, t1xr = nx ? ax.y : bx.y;
+                        const float t0yl = ny ? by.x : ay.x, t1yl = ny ? ay.x : by.x, t0yr = ny ? by.y : ay.y, t1yr = ny ? ay.y : by.y;
+                        const float t0zl = nz ? bz.x : az.x, t1zl = nz ? az.x : bz.x, t0zr = nz ? bz.y : az.y, t1zr = nz ? az.y : bz.y;
+                        const float tl = fmaxf(fmaxf(kTMin, t0xl), fmaxf(t0yl, t0zl)), tr = fmaxf(fmaxf(kTMin, t0xr), fmaxf(t0yr, t0zr));
+                        const bool hl = !(fminf(fminf(closest, t1xl), fminf(t1yl, t1zl)) <= tl);
+                        const bool hr = !(fminf(fminf(closest, t1xr), fminf(t1yr, t1zr)) <= tr);
                         // nearer child by box centre along the ray :433-453 (only matters when both are hit)
-                        const F3 cl = mk(0.5f * (l_lo.x + l_hi.x), 0.5f * (l_lo.y + l_hi.y), 0.5f * (l_lo.z + l_hi.z));
-                        const F3 cr = mk(0.5f * (r_lo.x + r_hi.x), 0.5f * (r_lo.y + r_hi.y), 0.5f * (r_lo.z + r_hi.z));
-                        const float dl = dot(cl - ro, rd), dr = dot(cr - ro, rd);
-                        const bool left_near = dl < dr;
+                        const v2f dc = (((lox + hix) * 0.5f - ro.x) * rd.x + ((loy + hiy) * 0.5f - ro.y) * rd.y) + ((loz + hiz) * 0.5f - ro.z) * rd.z;
+                        const bool left_near = dc.x < dc.y;
                         const bool both = hl && hr;
                         // the far child goes to stack[sp]; written unconditionally (slot sp is above the top, slot K is a dump
                         // slot for sp >= K), the stack only grows when both children were hit
@@ -229,8 +235,8 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
                     const float4* rec = S.pairs + (size_t)cur * 4;
                     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                     float tl, tr;
-                    const bool hl = slab(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), ro, rinv, kTMax, tl);
-                    const bool hr = slab(mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), ro, rinv, kTMax, tr);
+                    const bool hl = slab(mk(q0.x, q1.x, q2.x), mk(q0.z, q1.z, q2.z), ro, rinv, kTMax, tl);
+                    const bool hr = slab(mk(q0.y, q1.y, q2.y), mk(q0.w, q1.w, q2.w), ro, rinv, kTMax, tr);
                     const int rl = __float_as_int(q3.x), rr = __float_as_int(q3.y);
                     if (hl && hr) { if (sp < 64) stack[sp++] = rr; cur = rl; }
                     else if (hl) cur = rl;
@@ -321,13 +327,8 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
 }
 
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
-    switch (lds_entries) {
-    case 8:  return launch_k<8>(a, blocks, count, checked, anyhit, stream);
-    case 12: return launch_k<12>(a, blocks, count, checked, anyhit, stream);
-    case 16: return launch_k<16>(a, blocks, count, checked, anyhit, stream);
-    case 24: return launch_k<24>(a, blocks, count, checked, anyhit, stream);
-    default: return hipErrorInvalidValue;
-    }
+    if (lds_entries != 8) return hipErrorInvalidValue;     // 16 stacks of K+1 entries + continuation strip + tree top = 159,744 B of LDS at K = 8
+    return launch_k<8>(a, blocks, count, checked, anyhit, stream);
 }
 
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,

@@ -134,7 +134,7 @@ typedef struct DsrtRenderDesc {
     int      collect_counters;      /* 1 -> counting build of the kernel (fills DsrtStats); 2 -> counting build WITHOUT the any-hit
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
-    int      stack_entries;         /* LDS short-stack entries per lane: 0 -> default             */
+    int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, 1 = natural tile
                                        order instead of costliest-first} (see device_layout.h); none of them changes a pixel */
 } DsrtRenderDesc;
@@ -151,6 +151,8 @@ typedef struct DsrtStats {
     uint64_t node_slots, tri_slots, adv_slots, adv_active;
     /* where the idle lanes of the node loop were: parked at a leaf / waiting for their state machine / out of work */
     uint64_t idle_at_leaf, idle_waiting, idle_done;
+    /* node visits at BVH depth < 6 / 9 / 12 (root = 0) */
+    uint64_t visits_depth_lt6, visits_depth_lt9, visits_depth_lt12;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of

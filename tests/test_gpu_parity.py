@@ -63,18 +63,15 @@ def test_render_matches_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, name):
     assert st1.rays == want_cnt["rays"] and st1.tri_tests <= want_cnt["tri_tests"] and st1.nodes_entered <= want_cnt["nodes_entered"]
 
 
-@pytest.mark.parametrize("entries", [8, 12, 16, 24])
-def test_short_stack_sizes_and_spill_give_identical_images(dsrt, gpu_ctx, oracle, entries):
+@pytest.mark.parametrize("entries", [0, 8])
+def test_short_stack_and_spill_give_identical_images(dsrt, gpu_ctx, oracle, entries):
     hs, scene, W, H, spp, depth = _scene(dsrt, "station_near")
     want_rgb, _, want_cnt = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
     rgb, _, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=1, stack_entries=entries))
     assert np.array_equal(rgb, want_rgb)
-    assert st.lds_stack_entries == entries and st.max_stack == want_cnt["max_stack"]
-    if want_cnt["max_stack"] > entries:
-        assert st.stack_spills > 0          # the global-memory spill strip was really used
-    else:
-        assert st.stack_spills == 0
+    assert st.lds_stack_entries == 8 and st.max_stack == want_cnt["max_stack"] and want_cnt["max_stack"] > 8
+    assert st.stack_spills > 0              # this scene's walks go deeper than the LDS part: the global spill strip was really used
 
 
 def test_pose_frame_config_c2_shape(dsrt, gpu_ctx, oracle, tmp_path):
@@ -153,7 +150,7 @@ def test_empty_scene_and_argument_errors(dsrt, gpu_ctx):
     with pytest.raises(dsrt.DsrtError):
         gpu_ctx.render_to_host(dsrt.make_desc(32, 16, 2, 5, tile_size=12))
     with pytest.raises(dsrt.DsrtError):
-        gpu_ctx.render_to_host(dsrt.make_desc(32, 16, 2, 5, stack_entries=10))
+        gpu_ctx.render_to_host(dsrt.make_desc(32, 16, 2, 5, stack_entries=12))
     fresh = dsrt.Context(0)
     with pytest.raises(dsrt.DsrtError):
         fresh.render_to_host(dsrt.make_desc(32, 16, 2, 5))      # no scene uploaded

@@ -54,6 +54,7 @@ def main():
                             "tris_per_ray": round(sc.tri_tests / max(1, sc.rays), 2), "max_stack": sc.max_stack, "spills": sc.stack_spills,
                             "util_node": round(sc.internal_entered / max(1, sc.node_slots), 3), "util_tri": round(sc.tri_tests / max(1, sc.tri_slots), 3),
                             "util_adv": round(sc.adv_active / max(1, sc.adv_slots), 3),
+                            "visits_frac_depth_lt_6_9_12": [round(sc.visits_depth_lt6 / max(1, sc.internal_entered), 3), round(sc.visits_depth_lt9 / max(1, sc.internal_entered), 3), round(sc.visits_depth_lt12 / max(1, sc.internal_entered), 3)],
                             "node_idle_leaf_wait_done": [round(sc.idle_at_leaf / max(1, sc.node_slots), 3), round(sc.idle_waiting / max(1, sc.node_slots), 3), round(sc.idle_done / max(1, sc.node_slots), 3)],
                             "wave_iters_node_tri_adv": [sc.node_slots // 64, sc.tri_slots // 64, sc.adv_slots // 64]})
             print(json.dumps(rec), flush=True)
