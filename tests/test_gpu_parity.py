@@ -178,3 +178,58 @@ def test_drop_in_entry_points(dsrt, oracle, tmp_path):
     assert data.startswith(header) and data[len(header):] == want_rgb.tobytes()
     dsrt.lib.dsrt_free_gpu_scene(C.byref(dev))
     assert not dev.triangles and dev.num_triangles == 0 and not dev.bvh_nodes
+
+
+def test_full_size_frame_properties_and_oracle_rows(dsrt, gpu_ctx, oracle, tmp_path):
+    """BASELINE.json's metric size (1920x1080 @ 1000 spp, pose frame 98) on a 100k-triangle stand-in mesh.
+
+    The oracle cannot render 2 G samples in test time, so the whole frame is checked through properties that do not depend
+    on size -- idempotence (same bytes twice), independence from the order pixels are handed out in (costliest-first vs
+    natural), tile shards reassembling to the same frame -- and three full-width rows (1920 px x 1000 spp each) are checked
+    bit for bit against the oracle."""
+    import threading
+    import torch
+    from dsrt_amd import meshgen
+    obj = tmp_path / "iss_100k.obj"
+    meshgen.generate(obj, 100000)
+    hs = dsrt.HostScene().add_obj(obj)
+    hs.build_bvh()
+    poses = dsrt.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
+    W, H, spp = 1920, 1080, 1000
+    fr = dsrt.pose_to_frame(poses[98])
+    cam = dsrt.frame_camera(fr, 40.0, W, H, spp, 50)
+    scene = hs.view(cam, tuple(fr.sun_dir_model))
+    gpu_ctx.upload(scene)
+    first, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50), want_f32=True)
+    again, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50))
+    natural, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, tune=(0, 0, 0, 1)))
+    assert np.array_equal(first, again) and np.array_equal(first, natural)
+    assert (first.max(axis=2) > 0).mean() > 0.2            # the station fills a good part of this frame
+
+    world = 4
+    lay = dsrt.shard_layout(dsrt.make_desc(W, H, spp, 50, shard_count=world))
+    gathered = torch.zeros(world * lay["rgb8_bytes_padded"], dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        part = gathered[rank * lay["rgb8_bytes_padded"]:(rank + 1) * lay["rgb8_bytes_padded"]]
+        gpu_ctx.render(dsrt.make_desc(W, H, spp, 50, shard_rank=rank, shard_count=world), part.data_ptr(), stream=stream)
+    image = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    gpu_ctx.deinterleave(dsrt.make_desc(W, H, spp, 50, shard_count=world), gathered.data_ptr(), image.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), first)
+
+    rows = [540, 97, 1003]                                   # kernel rows (0 = bottom): centre, low, high
+    want = {}
+
+    def run(y):
+        want[y] = oracle.render(scene, W, H, y, y + 1)
+    threads = [threading.Thread(target=run, args=(y,)) for y in rows]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for y in rows:
+        rgb, ref32, _ = want[y]
+        r = H - 1 - y
+        assert np.array_equal(first[r], rgb[r]), f"row {y}: {(first[r] != rgb[r]).any(axis=1).sum()} pixels differ"
+        assert np.array_equal(f32[r].view(np.uint32), ref32[r].view(np.uint32))
