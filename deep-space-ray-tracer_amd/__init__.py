@@ -146,10 +146,10 @@ def write_ppm(path, rgb, width, height):
 
 
 def make_desc(width, height, spp, max_depth=50, gamma=2.0, seed=1337, tile_size=0, shard_rank=0, shard_count=0,
-              collect_counters=0, checked=0, stack_entries=0, tune=(0, 0, 0, 0)):
+              collect_counters=0, checked=0, stack_entries=0, tune=(0, 0, 0, 0), rng_mode=0):
     d = DsrtRenderDesc()
     d.width, d.height, d.spp, d.max_depth, d.gamma, d.seed = int(width), int(height), int(spp), int(max_depth), float(gamma), int(seed)
-    d.rng_mode = 0
+    d.rng_mode = int(rng_mode)
     d.tile_size, d.shard_rank, d.shard_count = int(tile_size), int(shard_rank), int(shard_count)
     d.collect_counters, d.checked, d.stack_entries = int(collect_counters), int(checked), int(stack_entries)
     for i, v in enumerate(tuple(tune) + (0,) * (4 - len(tune))):
@@ -214,6 +214,11 @@ class Context:
         _check(rc, "dsrt_render_to_host")
         shape = (desc.height, desc.width, 3)
         return rgb.reshape(shape), (f32.reshape(shape) if want_f32 else None), st
+
+    def selftest_philox(self, seed, subsequence, n):
+        ours, theirs = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        _check(lib.dsrt_selftest_philox(self._h, int(seed), int(subsequence), int(n), ours.ctypes.data, theirs.ctypes.data), "dsrt_selftest_philox")
+        return ours, theirs
 
     def selftest_math(self, fn, x, y=0.0):
         x = np.ascontiguousarray(x, np.float32)

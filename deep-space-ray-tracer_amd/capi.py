@@ -107,7 +107,7 @@ EXPORTS = [
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_write_ppm",
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_scene_upload", "dsrt_scene_upload_device",
     "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_render", "dsrt_deinterleave_tiles", "dsrt_render_to_host",
-    "dsrt_selftest_math", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
+    "dsrt_selftest_math", "dsrt_selftest_philox", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
 ]
 
 
@@ -151,6 +151,7 @@ def load():
     sig("dsrt_deinterleave_tiles", C.c_int, [vp, P(DsrtRenderDesc), vp, vp, vp])
     sig("dsrt_render_to_host", C.c_int, [vp, P(DsrtRenderDesc), vp, vp, P(DsrtStats)])
     sig("dsrt_selftest_math", C.c_int, [vp, C.c_int, vp, C.c_float, vp, C.c_int])
+    sig("dsrt_selftest_philox", C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp])
     sig("gpu_render_scene", None, [P(GPUScene), C.c_int, C.c_int])
     sig("dsrt_build_gpu_scene", C.c_int, [vp, P(GPUCamera), P(C.c_float), P(GPUScene)])
     sig("dsrt_free_gpu_scene", None, [P(GPUScene)])

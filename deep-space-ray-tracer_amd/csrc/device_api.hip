@@ -20,7 +20,9 @@
 #include "device_layout.h"
 
 namespace dsrt {
-hipError_t launch_render(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+hipError_t launch_resolve(const float* partial, int chunks, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
+hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
@@ -221,6 +223,7 @@ struct DsrtContext {
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order;
+    DevBuf<float> partial;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
 };
@@ -345,7 +348,7 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
 int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream_v, DsrtStats* stats) {
     if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
     if (!ctx->scene.valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
-    if (desc->rng_mode != 0) { set_error("dsrt_render: only rng_mode 0 (reference LCG stream) is implemented"); return DSRT_ERR_INVALID; }
+    if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
     Tiling t;
     if (!make_tiling(*desc, t)) { set_error("dsrt_render: bad size, tile or shard"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -370,11 +373,25 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     const float gamma = desc->gamma > 0.0f ? desc->gamma : 1.0f;        // :1043
     f.inv_gamma = 1.0f / gamma;
     f.seed32 = (uint32_t)(desc->seed & 0xFFFFFFFFu);
+    f.seed_hi = (uint32_t)(desc->seed >> 32);
     f.tile = t.tile; f.tiles_x = t.tiles_x; f.tiles_y = t.tiles_y;
     f.shard_rank = desc->shard_rank; f.shard_count = desc->shard_count > 1 ? desc->shard_count : 1;
     f.local_tiles = t.mine;
     f.total_items = (uint32_t)t.mine * (uint32_t)(t.tile * t.tile);
     f.compact_output = desc->shard_count > 1 ? 1 : 0;
+    f.chunks = 1; f.chunk_len = f.spp;
+    const size_t out_pixels = desc->shard_count > 1 ? (size_t)t.padded * t.tile * t.tile : (size_t)desc->width * desc->height;
+    if (desc->rng_mode == 1) {
+        // a pixel's samples are independent streams: split them into up to 16 work items per pixel
+        f.chunk_len = f.spp < 128 ? (f.spp + 7) / 8 : (f.spp + 15) / 16;
+        if (f.chunk_len < 1) f.chunk_len = 1;
+        f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
+        f.total_items *= (uint32_t)f.chunks;
+        const size_t words = out_pixels * (size_t)f.chunks * 3;
+        if (ctx->partial.n < words) { int rc = ctx->partial.alloc(words); if (rc) return rc; }
+        HIP_TRY(hipMemsetAsync(ctx->partial.p, 0, words * sizeof(float), stream));
+        a.partial = ctx->partial.p;
+    }
     a.out_rgb8 = d_rgb8;
     a.out_f32 = d_f32;
     a.queue = ctx->ctrl.p;
@@ -412,7 +429,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    HIP_TRY(launch_render(a, K, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.partial, f.chunks, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     if (stats) {
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -481,6 +499,19 @@ int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float*
     HIP_TRY(launch_math(fn, dx.p, y, dy.p, n, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dy.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return DSRT_OK;
+}
+
+int dsrt_selftest_philox(DsrtContext* ctx, uint64_t seed, uint64_t subsequence, int n, uint32_t* ours, uint32_t* rocrand_words) {
+    if (!ctx || !ours || !rocrand_words || n <= 0) { set_error("dsrt_selftest_philox: bad argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<uint32_t> a, b;
+    int rc;
+    if ((rc = a.alloc((size_t)n)) || (rc = b.alloc((size_t)n))) return rc;
+    HIP_TRY(launch_philox(seed, subsequence, n, a.p, b.p, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ours, a.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rocrand_words, b.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return DSRT_OK;
 }
 
@@ -559,6 +590,7 @@ void gpu_render_scene(const GPUScene* scene, int width, int height) {
     d.max_depth = scene->params.max_depth;
     d.gamma = scene->params.gamma;
     d.seed = scene->seed;
+    d.rng_mode = scene->params.rng_mode == 1 ? 1 : 0;        // the reference always stores 0 here (src/gpu_scene_builder.cpp:577)
     std::vector<uint8_t> fb((size_t)width * height * 3);
     if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, nullptr) != DSRT_OK) { std::fprintf(stderr, "render_kernel failed: %s\n", dsrt_last_error()); return; }
     if (dsrt_write_ppm("image_gpu.ppm", fb.data(), width, height) != DSRT_OK) std::fprintf(stderr, "Failed to open image_gpu.ppm for writing\n");

@@ -67,6 +67,8 @@ struct FrameParams {
     int   width, height, spp, max_depth;
     float inv_gamma;
     uint32_t seed32;
+    uint32_t seed_hi;          // rng_mode 1: upper half of the 64-bit seed (Philox key.y)
+    int   chunks, chunk_len;   // rng_mode 1: a pixel's spp samples are split into `chunks` work items of `chunk_len` samples
     int   tile;                // tile edge in pixels (multiple of 8)
     int   tiles_x, tiles_y;
     int   shard_rank, shard_count;
@@ -84,6 +86,7 @@ struct RenderArgs {
     uint32_t* queue;           // [0] next work item
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
+    float*    partial;         // rng_mode 1: [output pixel][chunk][3] partial sample sums
     uint2*    spill;           // stack overflow area: [(entry - K) * spill_stride + global lane]
     uint32_t  spill_stride;
     int       spill_entries;

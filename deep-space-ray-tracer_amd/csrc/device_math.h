@@ -31,12 +31,41 @@ __device__ __forceinline__ F3 clamp01(F3 a) {
 constexpr float kPi = 3.14159265358979323846f;                  // PI_F :96
 constexpr float kTMin = 0.001f, kTMax = 1e9f;                   // scene_hit(ray, 0.001f, 1e9f) :744, :816
 
+// rng_mode 0 -- the reference's generator: ONE 32-bit LCG stream per pixel, shared by all its samples (:77-80, :990).
 __device__ __forceinline__ float rand01(uint32_t& s) {          // :77-80
     s = s * 1664525u + 1013904223u;
     return (float)(s & 0x00FFFFFFu) / 16777216.0f;
 }
 
-__device__ __forceinline__ F3 random_in_unit_sphere(uint32_t& rng) {   // :82-91
+// rng_mode 1 -- rocRAND's Philox4x32-10, in stateless (counter) form.  Draw n of sample stream `sub` is word n & 3 of
+// ten_rounds(counter = (n >> 2, 0, sub.lo, sub.hi), key = seed), which is exactly what rocrand_init(seed, sub, 0, &st)
+// followed by n + 1 calls of rocrand(&st) returns (rocrand_philox4x32_10.h: seed() / restart() / next());
+// dsrt_selftest_philox checks that on the device against rocRAND's own engine.  Every (pixel, sample) has its own
+// sub-sequence, so samples are independent work items.  The 32-bit word is mapped to [0,1) like the LCG's: low 24 bits / 2^24.
+struct PhiloxStream {
+    uint32_t key0, key1;      // seed
+    uint32_t sub0, sub1;      // sub-sequence = pixel * spp + sample
+    uint32_t n;               // draws taken so far in this sub-sequence
+};
+__device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t which) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return which == 0 ? c0 : (which == 1 ? c1 : (which == 2 ? c2 : c3));
+}
+__device__ __forceinline__ float rand01(PhiloxStream& g) {
+    const uint32_t w = philox4x32_10_word(g.key0, g.key1, g.n >> 2, 0u, g.sub0, g.sub1, g.n & 3u);
+    g.n++;
+    return (float)(w & 0x00FFFFFFu) / 16777216.0f;
+}
+
+template <class Rng>
+__device__ __forceinline__ F3 random_in_unit_sphere(Rng& rng) {   // :82-91
     for (;;) {
         float x = rand01(rng) * 2.0f - 1.0f;
         float y = rand01(rng) * 2.0f - 1.0f;
@@ -48,7 +77,8 @@ __device__ __forceinline__ F3 random_in_unit_sphere(uint32_t& rng) {   // :82-91
 }
 
 // sample_cosine_hemisphere :121-141 with build_onb :112-118 and random_cosine_direction :99-109
-__device__ __forceinline__ F3 sample_cosine_hemisphere(F3 normal, uint32_t& rng, float& pdf) {
+template <class Rng>
+__device__ __forceinline__ F3 sample_cosine_hemisphere(F3 normal, Rng& rng, float& pdf) {
     F3 w = normalize(normal);
     F3 a = (fabsf(w.x) > 0.9f) ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
     F3 v = normalize(cross(w, a));
@@ -66,7 +96,8 @@ __device__ __forceinline__ F3 sample_cosine_hemisphere(F3 normal, uint32_t& rng,
 }
 
 // sample_sphere_light_direction :145-189
-__device__ __forceinline__ void sample_sphere_light(const GPUSphere& sph, F3 origin, uint32_t& rng, F3& dir, float& pdf) {
+template <class Rng>
+__device__ __forceinline__ void sample_sphere_light(const GPUSphere& sph, F3 origin, Rng& rng, F3& dir, float& pdf) {
     float z = 2.0f * rand01(rng) - 1.0f;
     float phi = 2.0f * kPi * rand01(rng);
     float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));

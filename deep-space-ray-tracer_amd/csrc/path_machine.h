@@ -7,6 +7,8 @@
 // advance_step() performs exactly ONE transition of a lane whose state is < ST_TRAV_CLOSEST.
 #pragma once
 
+#include <type_traits>
+
 #include "device_math.h"
 
 namespace dsrt {
@@ -22,7 +24,9 @@ constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps
 struct Lane {
     int state = ST_FETCH;
     int px = 0, ky = 0, sample = 0, depth = 0;
-    uint32_t out_index = 0, rng = 0;
+    uint32_t out_index = 0, rng = 0;             // rng: LCG state (rng_mode 0) or draws taken in the current sample (rng_mode 1)
+    int sample_end = 0;                          // rng_mode 1: this work item covers samples [.., sample_end) of the pixel
+    uint32_t chunk = 0;                          // rng_mode 1: which slice of the pixel's samples
     F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
     int cur = kRefNone, sp = 0, hit_slot = -1;
@@ -50,23 +54,45 @@ __device__ __forceinline__ void flush_counters(const RenderArgs& args, uint32_t*
     }
 }
 
-template <bool COUNT, bool CHECKED, bool ANYHIT>
+template <int RNGMODE> struct RngOf;
+template <> struct RngOf<0> { using type = uint32_t&; };
+template <> struct RngOf<1> { using type = PhiloxStream; };
+template <int RNGMODE>
+__device__ __forceinline__ typename RngOf<RNGMODE>::type make_rng(Lane& ln, const FrameParams& P) {
+    if constexpr (RNGMODE == 0) {
+        return ln.rng;
+    } else {
+        const unsigned long long sub = (unsigned long long)(uint32_t)(ln.px + ln.ky * P.width) * (unsigned long long)(uint32_t)P.spp + (unsigned long long)(uint32_t)ln.sample;
+        return PhiloxStream{P.seed32, P.seed_hi, (uint32_t)sub, (uint32_t)(sub >> 32), ln.rng};
+    }
+}
+
+template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
 __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, uint32_t* c, uint32_t& flags) {
     const DeviceScene& S = args.scene;
     const FrameParams& P = args.frame;
     int& state = ln.state; int& px = ln.px; int& ky = ln.ky; int& sample = ln.sample; int& depth = ln.depth;
-    uint32_t& out_index = ln.out_index; uint32_t& rng = ln.rng;
+    uint32_t& out_index = ln.out_index;
     F3& accum = ln.accum; F3& thr = ln.thr; F3& L = ln.L; F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
     int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
     float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v;
     uint32_t& steps = ln.steps;
     const int spp = P.spp;
     const int W = P.width, H = P.height;
+    // the generator the body below draws from: the lane's LCG word itself, or a Philox stream rebuilt from (pixel, sample, draws)
+    typename RngOf<RNGMODE>::type rng = make_rng<RNGMODE>(ln, P);
+    auto restream = [&]() {                      // rng_mode 1: point the generator at the current (pixel, sample), draw 0
+        if constexpr (RNGMODE == 1) {
+            const unsigned long long sub = (unsigned long long)(uint32_t)(px + ky * W) * (unsigned long long)(uint32_t)spp + (unsigned long long)(uint32_t)sample;
+            rng.sub0 = (uint32_t)sub; rng.sub1 = (uint32_t)(sub >> 32); rng.n = 0;
+        }
+    };
 
     // ray_color's return and the accumulate in render_kernel: clamp the SAMPLE to [0,1] (:935), add (:999), next sample.
     auto end_sample = [&]() {
         accum = accum + clamp01(L);
         sample++;
+        restream();
         state = ST_GEN;
     };
 
@@ -95,6 +121,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             state = ST_DONE;
         } else {
             const uint32_t tt = (uint32_t)(P.tile * P.tile);
+            if constexpr (RNGMODE == 1) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }   // slice fastest: a wave starts on few pixels
             const uint32_t within = item % tt;
             const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
@@ -106,14 +133,28 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                 px = x;
                 ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
                 out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
-                rng = (uint32_t)(px + ky * W) ^ P.seed32;       // :990
                 accum = mk(0, 0, 0);
-                sample = 0;
+                if constexpr (RNGMODE == 0) {
+                    rng = (uint32_t)(px + ky * W) ^ P.seed32;   // :990
+                    sample = 0;
+                    ln.sample_end = spp;
+                } else {
+                    sample = (int)ln.chunk * P.chunk_len;
+                    ln.sample_end = min(spp, sample + P.chunk_len);
+                    restream();
+                }
                 state = ST_GEN;
             }
         }
     } else if (state == ST_GEN) {
-        if (sample >= spp) {
+        if (RNGMODE == 1 && sample >= ln.sample_end) {
+            // this slice of the pixel's samples is done: its partial sum goes to the slice's own slot; dsrt_resolve_kernel
+            // adds the slices in order and tone-maps
+            float* dst = args.partial + ((size_t)out_index * (size_t)P.chunks + ln.chunk) * 3;
+            dst[0] = accum.x; dst[1] = accum.y; dst[2] = accum.z;
+            flush_counters<COUNT>(args, c);
+            state = ST_FETCH;
+        } else if (sample >= spp) {
             // tone map + store :1003-1030
             float inv_spp = 1.0f / (float)spp;
             F3 col = accum * inv_spp;
@@ -334,6 +375,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
         else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
     }
+    if constexpr (RNGMODE == 1) ln.rng = rng.n;
 }
 
 }  // namespace dsrt

@@ -24,12 +24,14 @@
 //     and shadow rays stop at the first accepted triangle (same boolean as the reference's closest-hit search).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math: IEEE div/sqrt are part of the contract).
+#include <rocrand/rocrand_kernel.h>
+
 #include "path_machine.h"
 
 namespace dsrt {
 constexpr int kWavesPerBlock = 4;
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const RenderArgs args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         for (int budget = 0; budget < args.advance_budget; ++budget) {
             if (!__any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
-            if (state < ST_TRAV_CLOSEST) advance_step<COUNT, CHECKED, ANYHIT>(ln, args, c, flags);
+            if (state < ST_TRAV_CLOSEST) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE>(ln, args, c, flags);
         }
 
         if (__all(state == ST_DONE)) break;
@@ -311,24 +313,66 @@ __global__ void dsrt_math_kernel(int fn, const float* __restrict__ x, float y, f
     out[i] = fn == 0 ? dsrt_sinf(x[i]) : (fn == 1 ? dsrt_cosf(x[i]) : dsrt_powf(x[i], y));
 }
 
+// rng_mode 1: add a pixel's sample slices in slice order, then the reference's tone map and 8-bit store (:1003-1030).
+__global__ void dsrt_resolve_kernel(const float* __restrict__ partial, int chunks, int spp, float inv_gamma, size_t n_pixels,
+                                    uint8_t* __restrict__ out_rgb8, float* __restrict__ out_f32) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    F3 acc = mk(0, 0, 0);
+    for (int k = 0; k < chunks; ++k) acc = acc + ld3(partial + (i * (size_t)chunks + (size_t)k) * 3);
+    const float inv_spp = 1.0f / (float)spp;
+    F3 col = acc * inv_spp;
+    col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
+    col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
+    col = mk(dsrt_powf(col.x, inv_gamma), dsrt_powf(col.y, inv_gamma), dsrt_powf(col.z, inv_gamma));
+    col = clamp01(col);
+    out_rgb8[i * 3 + 0] = (unsigned char)(255.99f * col.x);
+    out_rgb8[i * 3 + 1] = (unsigned char)(255.99f * col.y);
+    out_rgb8[i * 3 + 2] = (unsigned char)(255.99f * col.z);
+    if (out_f32) { out_f32[i * 3 + 0] = col.x; out_f32[i * 3 + 1] = col.y; out_f32[i * 3 + 2] = col.z; }
+}
+
 // ---- launchers (called from device_api.hip) -----------------------------------------------------------
-template <int K>
+template <int K, int RNGMODE>
 static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
     if (count) {
-        if (anyhit) hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, true>), grid, block, 0, stream, a);
-        else        hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, false>), grid, block, 0, stream, a);
+        if (anyhit) hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, true, RNGMODE>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, false, RNGMODE>), grid, block, 0, stream, a);
     } else if (checked) {
-        hipLaunchKernelGGL((dsrt_render_kernel<K, false, true, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, true, true, RNGMODE>), grid, block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE>), grid, block, 0, stream, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderArgs& a, int lds_entries, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
-    if (lds_entries != 8) return hipErrorInvalidValue;     // 16 stacks of K+1 entries + continuation strip + tree top = 159,744 B of LDS at K = 8
-    return launch_k<8>(a, blocks, count, checked, anyhit, stream);
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
+    if (lds_entries != 8) return hipErrorInvalidValue;     // the only short-stack size built
+    if (rng_mode == 0) return launch_k<8, 0>(a, blocks, count, checked, anyhit, stream);
+    if (rng_mode == 1) return launch_k<8, 1>(a, blocks, count, checked, anyhit, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_resolve(const float* partial, int chunks, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_resolve_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, partial, chunks, spp, inv_gamma, n_pixels, out_rgb8, out_f32);
+    return hipGetLastError();
+}
+
+// Test hook: the first n words of Philox sub-sequence `sub` from our stateless form and from rocRAND's own device engine.
+__global__ void dsrt_philox_kernel(unsigned long long seed, unsigned long long sub, int n, uint32_t* __restrict__ ours, uint32_t* __restrict__ theirs) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(seed, sub, 0, &st);
+    for (int i = 0; i < n; ++i) {
+        ours[i] = philox4x32_10_word((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i >> 2, 0u, (uint32_t)sub, (uint32_t)(sub >> 32), (uint32_t)i & 3u);
+        theirs[i] = rocrand(&st);
+    }
+}
+
+hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_philox_kernel, dim3(1), dim3(64), 0, stream, seed, sub, n, ours, theirs);
+    return hipGetLastError();
 }
 
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,

@@ -127,7 +127,9 @@ typedef struct DsrtRenderDesc {
     int      max_depth;             /* <=0 -> 12, as :723-725                                     */
     float    gamma;                 /* <=0 -> 1, as :1043                                         */
     uint64_t seed;
-    int      rng_mode;              /* 0 = reference LCG stream per pixel (parity mode)           */
+    int      rng_mode;              /* 0 = reference LCG stream per pixel (parity mode, bit-exact);
+                                       1 = rocRAND Philox4x32-10, one sub-sequence per (pixel, sample): samples become
+                                           independent work items (statistically equivalent image, not bit-identical to mode 0) */
     int      tile_size;             /* screen-tile edge in pixels, multiple of 8; 0 -> 8          */
     int      shard_rank;            /* this process renders tiles t with t % shard_count == shard_rank */
     int      shard_count;           /* 0 or 1 -> whole image                                      */
@@ -182,6 +184,10 @@ int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h
 /* Device evaluation of the shared deterministic math (tests): out[i] = f(x[i]) on the GPU;
  * fn 0 = sin, 1 = cos, 2 = pow(x[i], y).  Host pointers. */
 int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n);
+
+/* Device check that the kernel's stateless Philox4x32-10 equals rocRAND's engine: the first n 32-bit words of
+ * (seed, subsequence, offset 0) from both.  Host pointers. */
+int dsrt_selftest_philox(DsrtContext* ctx, uint64_t seed, uint64_t subsequence, int n, uint32_t* ours, uint32_t* rocrand_words);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

@@ -233,3 +233,44 @@ def test_full_size_frame_properties_and_oracle_rows(dsrt, gpu_ctx, oracle, tmp_p
         r = H - 1 - y
         assert np.array_equal(first[r], rgb[r]), f"row {y}: {(first[r] != rgb[r]).any(axis=1).sum()} pixels differ"
         assert np.array_equal(f32[r].view(np.uint32), ref32[r].view(np.uint32))
+
+
+def test_philox_stream_equals_rocrand(gpu_ctx):
+    # rng_mode 1 draws from rocRAND's Philox4x32-10: our stateless form vs rocrand_init + rocrand() on the device
+    for seed, sub in ((1337, 0), (1337, 123456789012), (0xDEADBEEFDEADBEEF, 2**40 + 5), (0, 2**63)):
+        ours, theirs = gpu_ctx.selftest_philox(seed, sub, 64)
+        assert np.array_equal(ours, theirs), (seed, sub)
+    a, _ = gpu_ctx.selftest_philox(1337, 1, 8)
+    b, _ = gpu_ctx.selftest_philox(1337, 2, 8)
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["station_near", "lights", "c1_spheres"])
+def test_rng_mode1_is_deterministic_shard_invariant_and_statistically_mode0(dsrt, gpu_ctx, oracle, name):
+    """rng_mode 1 (one Philox sub-sequence per (pixel, sample)) is NOT bit-identical to the reference's LCG mode by design;
+    it must be reproducible, independent of sharding / hand-out order, and the same image up to Monte-Carlo noise."""
+    import torch
+    hs, scene, W, H, _, depth = _scene(dsrt, name)
+    spp = 256
+    gpu_ctx.upload(scene)
+    m0, f0, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth), want_f32=True)
+    m1, f1, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, collect_counters=1), want_f32=True)
+    again, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, 1)))
+    assert np.array_equal(m1, again)                                   # same bytes, whatever the order of work
+    assert st.samples == W * H * spp
+    assert not np.array_equal(m0, m1)
+    d = f1.astype(np.float64) - f0.astype(np.float64)
+    assert abs(d.mean()) < 2e-3                                        # no bias ...
+    assert np.abs(d).mean() < 0.03                                     # ... and pixel differences at the noise level of 256 spp
+    # shards
+    world = 3
+    lay = dsrt.shard_layout(dsrt.make_desc(W, H, spp, depth, shard_count=world))
+    gathered = torch.zeros(world * lay["rgb8_bytes_padded"], dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        part = gathered[rank * lay["rgb8_bytes_padded"]:(rank + 1) * lay["rgb8_bytes_padded"]]
+        gpu_ctx.render(dsrt.make_desc(W, H, spp, depth, shard_rank=rank, shard_count=world, rng_mode=1), part.data_ptr(), stream=stream)
+    image = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    gpu_ctx.deinterleave(dsrt.make_desc(W, H, spp, depth, shard_count=world), gathered.data_ptr(), image.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), m1)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--stack", type=str, default="0")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--counters", action="store_true")
+    ap.add_argument("--rng", type=int, default=0)
     ap.add_argument("--tune", type=str, default="0:0:0", help="comma list of min_walk:adv_budget:leaf_ratio4")
     a = ap.parse_args()
     import dsrt_amd as d
@@ -43,12 +44,12 @@ def main():
         for K, tune in [(int(x), tuple(int(v) for v in t.split(":"))) for x in a.stack.split(",") for t in a.tune.split(",")]:
             best = None
             for _ in range(a.reps):
-                _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, tune=tune))
+                _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, tune=tune, rng_mode=a.rng))
                 best = st.kernel_ms if best is None else min(best, st.kernel_ms)
             rec = {"frame": fi, "sep_m": round(fr.sep_m, 1), "tris": hs.view().num_triangles, "WxHxspp": f"{W}x{H}x{spp}", "K": st.lds_stack_entries,
-                   "tune": tune, "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
+                   "rng_mode": a.rng, "tune": tune, "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
             if a.counters:
-                _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1, tune=tune))
+                _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1, tune=tune, rng_mode=a.rng))
                 rec.update({"coverage": round(sc.primary_hits / sc.samples, 4), "rays_per_sample": round(sc.rays / sc.samples, 3),
                             "Mrays_s": round(sc.rays / best / 1e3, 1), "nodes_per_ray": round(sc.nodes_entered / max(1, sc.rays), 2),
                             "tris_per_ray": round(sc.tri_tests / max(1, sc.rays), 2), "max_stack": sc.max_stack, "spills": sc.stack_spills,
