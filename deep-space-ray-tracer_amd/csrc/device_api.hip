@@ -27,7 +27,7 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, hipStream_t stream);
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, hipStream_t stream);
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -420,13 +420,18 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 24;
 
-    // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off)
-    if (desc->tune[3] != 1 && t.mine > 0) {
-        if (ctx->tile_cost.n < (size_t)t.mine) { int rc = ctx->tile_cost.alloc((size_t)t.mine); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine); if (rc) return rc; }
-        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, stream));
-        a.frame.tile_order = ctx->tile_order.p;
-    }
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
+    // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off); the word 32 entries past
+    // the cost array receives the number of tiles that see geometry
+    if (ctx->tile_cost.n < (size_t)t.mine + 64) { int rc = ctx->tile_cost.alloc((size_t)t.mine + 64); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine + 64); if (rc) return rc; }
+    uint32_t* n_heavy = ctx->tile_cost.p + t.mine + 32;
+    a.n_heavy = n_heavy;
+    if (desc->tune[3] != 1 && t.mine > 0) {
+        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, n_heavy, stream));
+        a.frame.tile_order = ctx->tile_order.p;
+    } else {
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n_heavy, t.mine, 1, stream));
+    }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
     HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));

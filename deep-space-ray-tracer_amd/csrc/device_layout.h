@@ -84,6 +84,7 @@ struct RenderArgs {
     uint8_t*  out_rgb8;
     float*    out_f32;
     uint32_t* queue;           // [0] next work item
+    const uint32_t* n_heavy;   // rng_mode 1: number of tiles (first in tile_order) whose pixels are handed out in sample slices
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
     float*    partial;         // rng_mode 1: [output pixel][chunk][3] partial sample sums

@@ -117,11 +117,21 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
 
     if (state == ST_FETCH) {
         uint32_t item = atomicAdd(args.queue, 1u);
-        if (item >= P.total_items) {
+        const uint32_t tt = (uint32_t)(P.tile * P.tile);
+        bool sliced = false;
+        if constexpr (RNGMODE == 1) {
+            // Only pixels of tiles that see geometry are cut into sample slices (slice fastest: a wave starts on few pixels);
+            // background tiles, which come last in the costliest-first order, stay one work item per pixel.
+            // *args.n_heavy = number of such tiles, written by the tile-order pre-pass (its own cache line: the queue word's
+            // line is busy with atomics).
+            const uint32_t heavy_pixels = *args.n_heavy * tt, heavy_items = heavy_pixels * (uint32_t)P.chunks;
+            sliced = item < heavy_items;
+            if (sliced) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }
+            else { ln.chunk = 0; item = item - heavy_items + heavy_pixels; }
+        }
+        if (item >= (uint32_t)P.local_tiles * tt) {
             state = ST_DONE;
         } else {
-            const uint32_t tt = (uint32_t)(P.tile * P.tile);
-            if constexpr (RNGMODE == 1) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }   // slice fastest: a wave starts on few pixels
             const uint32_t within = item % tt;
             const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
@@ -139,8 +149,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     sample = 0;
                     ln.sample_end = spp;
                 } else {
-                    sample = (int)ln.chunk * P.chunk_len;
-                    ln.sample_end = min(spp, sample + P.chunk_len);
+                    sample = sliced ? (int)ln.chunk * P.chunk_len : 0;
+                    ln.sample_end = sliced ? min(spp, sample + P.chunk_len) : spp;
                     restream();
                 }
                 state = ST_GEN;

@@ -272,24 +272,24 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
 }
 
 // One block: counting sort of the shard's tiles by cost, costliest first (65 bins; order inside a bin does not matter).
-__global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile) {
+__global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile, uint32_t* __restrict__ n_heavy) {
     __shared__ uint32_t bins[65], cursor[65];
     const uint32_t full = (uint32_t)(tile * tile);
     for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
     __syncthreads();
     for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&bins[64u - min(64u, cost[t] * 64u / full)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } }
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } *n_heavy = (uint32_t)n - bins[64]; }
     __syncthreads();
     for (int t = threadIdx.x; t < n; t += blockDim.x) order[atomicAdd(&cursor[64u - min(64u, cost[t] * 64u / full)], 1u)] = (uint32_t)t;
 }
 
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, hipStream_t stream) {
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, hipStream_t stream) {
     const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));
     hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost);
-    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, n_heavy);
     return hipGetLastError();
 }
 
