@@ -37,6 +37,20 @@ def algorithmic_bytes(st, pixels):
             24 * st.sphere_tests + 12 * st.tex_fetches + 3 * pixels)
 
 
+def traffic_from_profile(n_tris, frame, W, H, spp, depth):
+    """HBM-side bytes per launch of the render kernel from the committed PMC profile (profiles/traffic_bench_default.json:
+    FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes, gfx950 read-side correction applied), if and only if it was
+    taken on this very workload; otherwise null."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_bench_default.json")))
+    except (OSError, ValueError):
+        return None
+    w = t.get("workload", {})
+    same = (w.get("mesh_triangles") == n_tris and w.get("frame") == frame and w.get("width") == W and w.get("height") == H and
+            w.get("spp") == spp and w.get("max_depth") == depth and w.get("rng_mode") == 0)
+    return t.get("hbm_bytes_corrected") if same else None
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, the cgroup quota, and never more than the 16 a one-GPU box grants."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -241,7 +255,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (my_bytes / (my_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if my_kernel_ms > 0 else None,
-                "traffic": None,
+                "traffic": traffic_from_profile(n_tris, args.frame, W, H, spp, depth) if n_gpus == 1 else None,
                 "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms, "algorithmic_bytes_per_launch": my_bytes,
                 "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path, "
                         "working set sits in L2/Infinity Cache (SURVEY.md H6), so a low HBM fraction is expected",
