@@ -93,6 +93,43 @@ def cpu_baseline(d, scene, W, H, spp, budget_s):
             "sample": f"{rows} rows starting at row {max(0, H // 2 - cores)} of the same frame at {W}x{H}x{spp} ({rows * W} pixels), {dt:.1f} s wall"}
 
 
+def book_baseline(obj_path, fr, cores):
+    """The book-style CPU render BASELINE.json names: the reference's own hittable_list / sphere / triangle_mesh / material
+    classes (compiled from /root/reference into oracle/_ref/book_render, prebuilt) under our book-style pixel loop.
+      * config C1 in full: the RTIOW three-sphere scene, 200x112 @ 16 spp, one process per core on disjoint row bands
+        (the classes draw from rand(), whose process-wide lock stops threads of one process from scaling);
+      * the ISS mesh: triangle_mesh::hit is a linear scan over all triangles, so a 24x14 @ 1 spp corner of the bench frame is
+        timed on one core and the rate is quoted as measured (linear in samples)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "book_render")
+    if not os.path.exists(exe):
+        return None
+    assets = os.path.join(ROOT, "tests", "golden", "assets")
+    H = 112
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([exe, "c1_spheres.world", "200", str(H), "16", "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", "-",
+                               str(H * i // cores), str(H * (i + 1) // cores)], cwd=assets, stdout=subprocess.PIPE, text=True) for i in range(cores)]
+    outs = [json.loads(p.communicate(timeout=300)[0]) for p in procs]
+    wall = time.perf_counter() - t0
+    c1 = {"workload": "RTIOW 3 spheres + ground (tests/golden/assets/c1_spheres.world), 200x112 @ 16 spp, max_depth 50", "cores": cores,
+          "Msamples/s": sum(o["samples"] for o in outs) / max(o["seconds"] for o in outs) / 1e6, "wall_s": wall}
+    iss = None
+    try:
+        world = f"/tmp/dsrt_book_{os.getpid()}.world"
+        with open(world, "w") as f:
+            f.write(f"obj {obj_path}\n")
+        sun = [str(v) for v in fr.sun_dir_model]
+        cam = [str(v) for v in fr.cam_in_model]
+        out = subprocess.run([exe, world, "24", "14", "1", "50", "1", *cam, "0", "0", "0", "40", *sun], stdout=subprocess.PIPE, text=True, timeout=240)
+        r = json.loads(out.stdout)
+        iss = {"workload": "bench mesh and pose, 24x14 @ 1 spp, max_depth 50 (triangle_mesh::hit scans every triangle per ray)", "cores": 1,
+               "Msamples/s": r["msamples_per_s"], "seconds": r["seconds"]}
+        os.remove(world)
+    except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported as such, it never stops the bench
+        iss = {"error": str(e)[:200]}
+    return {"kind": "reference classes + our book-style loop (oracle/book_render_driver.cpp)", "c1": c1, "iss_mesh": iss}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +302,8 @@ def main():
             out["extras"] = extras
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget)
+            if not args.no_extras:
+                out["cpu_baseline_book"] = book_baseline(obj, fr, host_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

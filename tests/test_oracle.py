@@ -145,3 +145,25 @@ def test_libm_variant_is_statistically_the_same(dsrt, oracle, oracle_libm):
     diff = np.abs(a.astype(int) - b.astype(int))
     assert (diff.max(axis=2) > 0).mean() < 0.05
     assert abs(a.astype(float).mean() - b.astype(float).mean()) < 0.5
+
+
+def test_book_style_baseline_runs_on_c1(tmp_path):
+    # oracle/_ref/book_render = the reference's own CPU classes under our book-style loop (BASELINE.json configs[0]).
+    import subprocess
+    from conftest import ASSETS, ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "book_render")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/book_render not built (needs /root/reference)")
+    out = tmp_path / "c1.ppm"
+    r = subprocess.run([exe, "c1_spheres.world", "100", "56", "4", "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", str(out)],
+                       cwd=ASSETS, stdout=subprocess.PIPE, text=True, check=True)
+    rep = json.loads(r.stdout)
+    assert rep["samples"] == 100 * 56 * 4 and rep["seconds"] > 0
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n100 56\n255\n")
+    img = np.frombuffer(data[len(b"P6\n100 56\n255\n"):], np.uint8).reshape(56, 100, 3)
+    assert (img.max(axis=2) > 0).mean() > 0.3          # ground + spheres are lit by the sun term
+    # a row band renders only its rows
+    r2 = subprocess.run([exe, "c1_spheres.world", "100", "56", "4", "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", "-", "10", "20"],
+                        cwd=ASSETS, stdout=subprocess.PIPE, text=True, check=True)
+    assert json.loads(r2.stdout)["samples"] == 100 * 10 * 4
