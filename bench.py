@@ -130,6 +130,67 @@ def book_baseline(obj_path, fr, cores):
     return {"kind": "reference classes + our book-style loop (oracle/book_render_driver.cpp)", "c1": c1, "iss_mesh": iss}
 
 
+def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name):
+    """BASELINE.json configs[4]: the whole pose file as one job.  The scene stays resident; per frame only camera and sun
+    change (the reference rebuilds and re-uploads everything per frame, src/main.cpp:405).  Frame k's image is copied to
+    pinned host memory on a side stream while frame k+1 renders (two device and two host buffers)."""
+    import torch
+    import torch.distributed as dist
+    shard = world if world > 1 else 0
+    render_stream = torch.cuda.current_stream()
+    copy_stream = torch.cuda.Stream()
+    lay = d.shard_layout(d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard))
+    part = torch.zeros(lay["rgb8_bytes_padded"] if shard else W * H * 3, dtype=torch.uint8, device=dev)
+    images = [torch.zeros(W * H * 3, dtype=torch.uint8, device=dev) for _ in range(2)] if rank == 0 else None
+    host = [torch.empty(W * H * 3, dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
+    done = [torch.cuda.Event() for _ in range(2)]
+    frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
+
+    def render_frame(i, slot):
+        fr, cam, _ = frame_scene(i)
+        ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+        desc = d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard, rng_mode=args.rng_mode)
+        if rank == 0:
+            render_stream.wait_event(done[slot])                     # the copy that last read this slot has finished
+        target = part if shard else images[slot]
+        ctx.render(desc, target.data_ptr(), stream=render_stream.cuda_stream)
+        if shard:
+            flat = shard_mod.gather_to_root(part, world, rank)
+            if rank == 0:
+                ctx.deinterleave(desc, flat.data_ptr(), images[slot].data_ptr(), stream=render_stream.cuda_stream)
+        if rank == 0:
+            ready = torch.cuda.Event()
+            ready.record(render_stream)
+            copy_stream.wait_event(ready)
+            with torch.cuda.stream(copy_stream):
+                host[slot].copy_(images[slot], non_blocking=True)
+                done[slot].record(copy_stream)
+
+    render_frame(frames[0], 0)                                        # warm-up (not timed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for n, i in enumerate(frames):
+        render_frame(i, n & 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/s (pose sequence, 1920x1080, scene resident, frame k copied out while k+1 renders)",
+            "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": 1,
+            "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
+            "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
+                                   f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +207,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--stack-entries", type=int, default=0)
+    ap.add_argument("--sequence", action="store_true", help="config 5: render every pose of the file once (default 250 spp) and report frames/s")
+    ap.add_argument("--rng-mode", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -169,6 +232,8 @@ def main():
 
     # ---- scene: mesh -> flatten -> BVH (host), upload + re-layout (device).  Not timed. ----
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
+    if args.sequence and spp == 1000:
+        spp = 250                                   # BASELINE.json configs[4]
     if args.obj:
         obj, mesh_name = args.obj, os.path.basename(args.obj)
     else:
@@ -194,6 +259,13 @@ def main():
     fr, cam, scene = frame_scene(args.frame)
     ctx.upload(scene)
     n_tris = scene.num_triangles
+
+    if args.sequence:
+        run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     shard = n_gpus if n_gpus > 1 else 0
     desc = d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard, stack_entries=args.stack_entries)
