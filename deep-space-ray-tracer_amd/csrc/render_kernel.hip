@@ -8,18 +8,21 @@
 //
 // How it computes it is not the reference's one-thread-per-pixel loop:
 //   * Persistent lanes.  A lane owns one pixel at a time (the reference's LCG makes the samples of a pixel one
-//     serial stream, :990-999) and pulls the next pixel from a global queue when it finishes, so a wave never
-//     idles behind its slowest pixel.  Work items are 8x8-pixel blocks in queue order: a wave starts coherent.
-//   * A lane is a small state machine (fetch pixel / start sample / start bounce / traverse / shade / shadow).
-//     The wave alternates between an ADVANCE phase (all non-traversing lanes step their state machine) and a
-//     TRAVERSE phase (all lanes with a live ray walk the BVH together); the traverse phase is left as soon as
-//     fewer lanes are walking than waiting (ballot + popcount), which keeps both phases mostly full although
-//     bounce depths diverge from 1 to 50.
-//   * Node visit = ONE 64-byte record with both child boxes (device_layout.h); the chosen child is not
-//     re-tested on entry and a postponed child carries its slab entry distance on the stack, so a pop is a
-//     single compare.  Both are bit-identical to the reference's re-tests: see `slab()` and the pop below.
-//   * The traversal stack is a short stack in LDS, [entry][lane] so the 64 lanes of a wave hit 64 different
-//     banks; entries beyond the LDS part spill to a per-lane strip in global memory (rare).
+//     serial stream, :990-999) and pulls the next from a global queue when it finishes, so a wave never idles behind
+//     its slowest pixel.  Work items are 8x8-pixel blocks, handed out costliest tile first (scheduling pre-pass
+//     below); with rng_mode 1 (a Philox sub-sequence per sample) the items are slices of a pixel's samples.
+//   * A lane is a small state machine (path_machine.h).  The wave alternates between an ADVANCE phase (all lanes
+//     that are not walking a ray step their state machine) and a TRAVERSE phase (all lanes with a live ray walk the
+//     BVH together, "while-while": node visits together, parked leaves together); phases are left when the lane-slots
+//     wasted by the lanes waiting for the other phase exceed what switching costs (ballot + popcount per iteration),
+//     which keeps the loops about half full although bounce depths diverge from 1 to 50.
+//   * Node visit = ONE 64-byte record with both child boxes, interleaved so the slab arithmetic runs on packed fp32
+//     pairs (device_layout.h); the chosen child is not re-tested on entry and a postponed child carries its slab
+//     entry distance on the stack, so a pop is a single compare.  Both are bit-identical to the reference's re-tests:
+//     see `slab()` in device_math.h and the pop below.
+//   * The traversal stack is a short stack in LDS, [entry][lane] so the 64 lanes of a wave hit 64 different banks;
+//     entries beyond the LDS part spill to a per-lane strip in global memory (rare, behind a wave-uniform guard).
+//     The continuation a lane postpones while its shadow ray is in flight also waits in LDS, not in registers.
 //   * The hit record is assembled once per ray from (slot, t, u, v) instead of on every accepted candidate,
 //     and shadow rays stop at the first accepted triangle (same boolean as the reference's closest-hit search).
 //
