@@ -46,7 +46,7 @@ class HostScene:
         self._built = False
 
     def close(self):
-        if self._h:
+        if self._h and lib is not None:
             lib.dsrt_host_scene_destroy(self._h)
             self._h = None
 
@@ -177,7 +177,7 @@ class Context:
         self.device = int(device)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.dsrt_ctx_destroy(self._h)
             self._h = None
 

@@ -4,7 +4,7 @@ Why it exists: the mesh every reference number is quoted on -- ../../iss_model/I
 outside the reference repository and not in this container, and there is no network.  This stand-in has the
 station's overall proportions in metres in the model frame the reference renders in (camera on +Z looking at the origin,
 src/main.cpp:399): a ~109 m lattice truss along X, eight solar-array wings of ~35 x 11.6 m in the X-Y plane, pressurised
-modules as cylinders along Z and X, radiators, and a handful of small parts.  The MTL exercises every branch of the
+modules as cylinders along Z and X, radiators, and a handful of small parts, written in a fixed generic attitude (see _attitude).  The MTL exercises every branch of the
 reference's material heuristics (inc/triangle_mesh.h:75-112): Kd-only -> lambertian, |Ks| > 0.05 -> metal with
 fuzz = 100/(Ns+100), d < 0.999 -> dielectric.  Triangle count is a parameter; every figure we report names it.
 A real ISS OBJ can be used instead wherever a mesh path is accepted.
@@ -247,6 +247,20 @@ def build_station(target_triangles):
     return _build(hi)
 
 
+def _attitude():
+    """Fixed, generic attitude of the station in its model frame: yaw 11.3, pitch 7.1, roll 4.7 degrees.
+
+    Not cosmetic.  Built axis-aligned, half of the triangles end up in BVH leaves whose box has zero thickness (a few coplanar
+    panel triangles), and the reference's slab test rejects such a box outright (`t_max <= t_min` with equality,
+    src/gpu_render.cu:312): the reference -- and therefore this renderer -- would not see them at all, and the benchmark would
+    trace rays through an invisible truss.  A real model is never exactly aligned with the axes everywhere; neither is this one."""
+    ay, ax, az = (math.radians(v) for v in (11.3, 7.1, 4.7))
+    ry = np.array([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+    rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+    rz = np.array([[math.cos(az), -math.sin(az), 0], [math.sin(az), math.cos(az), 0], [0, 0, 1]])
+    return rz @ rx @ ry
+
+
 def write_obj(mesh, obj_path, mtl_name=None):
     obj_path = str(obj_path)
     mtl_name = mtl_name or (os.path.splitext(os.path.basename(obj_path))[0] + ".mtl")
@@ -255,7 +269,9 @@ def write_obj(mesh, obj_path, mtl_name=None):
     with open(obj_path, "w") as f:
         f.write("# procedural ISS-like mesh (deep-space-ray-tracer_amd/meshgen.py)\n")
         f.write(f"mtllib {mtl_name}\n")
+        rot = _attitude()
         for v in mesh.verts:
+            v = (np.asarray(v, np.float64) @ rot.T).astype(np.float32)
             f.write("".join("v %.9g %.9g %.9g\n" % (float(a), float(b), float(c)) for a, b, c in v))
         for material, faces in mesh.faces:
             f.write(f"usemtl {material}\n")
