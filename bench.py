@@ -37,7 +37,7 @@ def algorithmic_bytes(st, pixels):
             24 * st.sphere_tests + 12 * st.tex_fetches + 3 * pixels)
 
 
-def traffic_from_profile(n_tris, frame, W, H, spp, depth):
+def traffic_from_profile(n_tris, frame, W, H, spp, depth, mesh_version):
     """HBM-side bytes per launch of the render kernel from the committed PMC profile (profiles/traffic_bench_default.json:
     FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes, gfx950 read-side correction applied), if and only if it was
     taken on this very workload; otherwise null."""
@@ -47,7 +47,7 @@ def traffic_from_profile(n_tris, frame, W, H, spp, depth):
         return None
     w = t.get("workload", {})
     same = (w.get("mesh_triangles") == n_tris and w.get("frame") == frame and w.get("width") == W and w.get("height") == H and
-            w.get("spp") == spp and w.get("max_depth") == depth and w.get("rng_mode") == 0)
+            w.get("spp") == spp and w.get("max_depth") == depth and w.get("rng_mode") == 0 and w.get("mesh_version") == mesh_version)
     return t.get("hbm_bytes_corrected") if same else None
 
 
@@ -237,14 +237,14 @@ def main():
     if args.obj:
         obj, mesh_name = args.obj, os.path.basename(args.obj)
     else:
-        obj = f"/tmp/dsrt_bench_station_{args.tris}.obj"
+        obj = f"/tmp/dsrt_bench_station_v{meshgen.VERSION}_{args.tris}.obj"
         if rank == 0 and not os.path.exists(obj):
             tmp = obj + f".{os.getpid()}.tmp"
             meshgen.write_obj(meshgen.build_station(args.tris), tmp, mtl_name=os.path.basename(obj)[:-4] + ".mtl")
             os.replace(tmp, obj)
         if world > 1:
             dist.barrier()
-        mesh_name = f"procedural ISS-like stand-in (meshgen.py), target {args.tris} triangles"
+        mesh_name = f"procedural ISS-like stand-in (meshgen.py v{meshgen.VERSION}), target {args.tris} triangles"
     hs = d.HostScene().add_obj(obj)
     hs.build_bvh()
     poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
@@ -364,7 +364,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (my_bytes / (my_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if my_kernel_ms > 0 else None,
-                "traffic": traffic_from_profile(n_tris, args.frame, W, H, spp, depth) if n_gpus == 1 else None,
+                "traffic": traffic_from_profile(n_tris, args.frame, W, H, spp, depth, None if args.obj else meshgen.VERSION) if n_gpus == 1 else None,
                 "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms, "algorithmic_bytes_per_launch": my_bytes,
                 "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path, "
                         "working set sits in L2/Infinity Cache (SURVEY.md H6), so a low HBM fraction is expected",

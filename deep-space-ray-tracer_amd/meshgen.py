@@ -14,6 +14,8 @@ import os
 
 import numpy as np
 
+VERSION = "2-attitude"        # bump when the generated geometry changes: profiles and bench lines name it
+
 MATERIALS = """# materials for the procedural ISS-like mesh
 newmtl module_white
 Kd 0.85 0.85 0.82

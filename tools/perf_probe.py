@@ -24,7 +24,7 @@ def main():
     a = ap.parse_args()
     import dsrt_amd as d
     from dsrt_amd import meshgen
-    obj = f"/tmp/dsrt_bench_station_{a.tris}.obj"
+    obj = f"/tmp/dsrt_bench_station_v{meshgen.VERSION}_{a.tris}.obj"
     if not os.path.exists(obj):
         meshgen.write_obj(meshgen.build_station(a.tris), obj)
     hs = d.HostScene().add_obj(obj)
