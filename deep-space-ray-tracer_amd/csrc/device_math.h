@@ -7,6 +7,12 @@
 
 namespace dsrt {
 
+// Wave votes straight from the compare mask (HIP's __ballot/__any/__all take an int and cost a v_cndmask + v_cmp each).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
+
 typedef float v2f __attribute__((ext_vector_type(2)));     // a (left, right) pair: maps onto the packed fp32 VALU ops
 
 struct F3 { float x, y, z; };

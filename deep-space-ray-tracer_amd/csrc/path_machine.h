@@ -4,7 +4,10 @@
 //   ST_FETCH        a pixel from the work queue                  ST_GEN          start the next sample / finish the pixel
 //   ST_BOUNCE       top of ray_color's depth loop (:727-744)     ST_SHADE        closest-hit result is in (hit_slot, closest, u, v)
 //   ST_SHADOW_DONE  shadow-ray result is in hit_slot             ST_TRAV_*       a ray is ready / being walked through the BVH
-// advance_step() performs exactly ONE transition of a lane whose state is < ST_TRAV_CLOSEST.
+// advance_step() takes a lane whose state is < ST_TRAV_CLOSEST as far as it can go without walking a ray.  The state blocks are
+// laid out in the order paths flow through them (SHADOW_DONE -> SHADE -> BOUNCE -> FETCH -> GEN -> ray start), each executed
+// once per call by all lanes that are in that state when control reaches it, so one call normally ends with every lane either
+// walking a new ray or done; the ray start (reciprocals, root-box test) is shared by all three kinds of ray.
 #pragma once
 
 #include <type_traits>
@@ -96,115 +99,25 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         state = ST_GEN;
     };
 
-    // Set up the traversal of the ray in (ro, rd).  Mirrors the head of bvh_hit_closest :394-410: the root box is
-    // tested first; a miss means the BVH contributes nothing and the lane goes straight to `after`.
-    auto start_ray = [&](int trav_state, int after) {
-        if (COUNT) c[C_RAYS]++;
-        rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        closest = kTMax;
-        hit_slot = -1;
-        sp = 0;
-        steps = 0;
-        state = after;
-        if (S.root_ref != kRefNone) {
-            if (COUNT) c[C_BOX_FETCHES]++;
-            float t_entry;
-            if (slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state = trav_state; }
-        }
-        // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
-        if (state == ST_SHADE && S.num_spheres == 0) end_sample();
-    };
+    int launch = 0;         // set by a block that leaves a new ray in (ro, rd): 1 = closest-hit ray, 2 = shadow ray
 
-    if (state == ST_FETCH) {
-        uint32_t item = atomicAdd(args.queue, 1u);
-        const uint32_t tt = (uint32_t)(P.tile * P.tile);
-        bool sliced = false;
-        if constexpr (RNGMODE == 1) {
-            // Only pixels of tiles that see geometry are cut into sample slices (slice fastest: a wave starts on few pixels);
-            // background tiles, which come last in the costliest-first order, stay one work item per pixel.
-            // *args.n_heavy = number of such tiles, written by the tile-order pre-pass (its own cache line: the queue word's
-            // line is busy with atomics).
-            const uint32_t heavy_pixels = *args.n_heavy * tt, heavy_items = heavy_pixels * (uint32_t)P.chunks;
-            sliced = item < heavy_items;
-            if (sliced) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }
-            else { ln.chunk = 0; item = item - heavy_items + heavy_pixels; }
-        }
-        if (item >= (uint32_t)P.local_tiles * tt) {
-            state = ST_DONE;
-        } else {
-            const uint32_t within = item % tt;
-            const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
-            const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
-            const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
-            const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;
-            const uint32_t in_x = (sub % per_row) * 8u + (l & 7u), in_y = (sub / per_row) * 8u + (l >> 3);
-            const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
-            if (x < W && row < H) {
-                px = x;
-                ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
-                out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
-                accum = mk(0, 0, 0);
-                if constexpr (RNGMODE == 0) {
-                    rng = (uint32_t)(px + ky * W) ^ P.seed32;   // :990
-                    sample = 0;
-                    ln.sample_end = spp;
-                } else {
-                    sample = sliced ? (int)ln.chunk * P.chunk_len : 0;
-                    ln.sample_end = sliced ? min(spp, sample + P.chunk_len) : spp;
-                    restream();
-                }
-                state = ST_GEN;
+    if (state == ST_SHADOW_DONE) {
+        // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
+        bool blocked = hit_slot >= 0;
+        if (!blocked || !ANYHIT) {
+            for (int i = 0; i < S.num_spheres; ++i) {
+                if (COUNT) c[C_SPHERE_TESTS]++;
+                float t_hit; F3 n_hit;
+                if (hit_sphere(S.spheres[i], ro, rd, closest, t_hit, n_hit)) { blocked = true; closest = t_hit; }
             }
+        } else if (COUNT) {
+            c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
         }
-    } else if (state == ST_GEN) {
-        if (RNGMODE == 1 && sample >= ln.sample_end) {
-            // this slice of the pixel's samples is done: its partial sum goes to the slice's own slot; dsrt_resolve_kernel
-            // adds the slices in order and tone-maps
-            float* dst = args.partial + ((size_t)out_index * (size_t)P.chunks + ln.chunk) * 3;
-            dst[0] = accum.x; dst[1] = accum.y; dst[2] = accum.z;
-            flush_counters<COUNT>(args, c);
-            state = ST_FETCH;
-        } else if (sample >= spp) {
-            // tone map + store :1003-1030
-            float inv_spp = 1.0f / (float)spp;
-            F3 col = accum * inv_spp;
-            col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
-            col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
-            col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
-            col = clamp01(col);
-            const size_t o = (size_t)out_index * 3;
-            args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
-            args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
-            args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
-            if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
-            flush_counters<COUNT>(args, c);
-            state = ST_FETCH;
-        } else {
-            float jx = ((float)sample + rand01(rng)) / (float)spp;          // :995-996
-            float jy = ((float)sample + rand01(rng)) / (float)spp;
-            float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
-            float v = ((float)ky + jy) / (float)(H - 1);
-            const F3 cam_o = ld3(P.cam_origin), cam_llc = ld3(P.cam_llc), cam_h = ld3(P.cam_horizontal), cam_v = ld3(P.cam_vertical);
-            ro = cam_o;
-            rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
-            depth = 0;
-            L = mk(0, 0, 0);
-            thr = mk(1, 1, 1);
-            if (COUNT) c[C_SAMPLES]++;
-            start_ray(ST_TRAV_CLOSEST, ST_SHADE);      // depth 0: no roulette, max_depth >= 1 (host guarantees)
-        }
-    } else if (state == ST_BOUNCE) {
-        // top of the depth loop :727-744
-        bool go = depth < P.max_depth;
-        if (go && depth >= 5) {
-            float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
-            p = fminf(p, 0.95f);
-            if (rand01(rng) > p) go = false;
-            else thr = thr * (1.0f / p);
-        }
-        if (!go) end_sample();
-        else start_ray(ST_TRAV_CLOSEST, ST_SHADE);
-    } else if (state == ST_SHADE) {
+        if (!blocked) L = L + pend_get(ln, 0);
+        if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
+        else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
+    }
+    if (state == ST_SHADE) {
         // ---- finish scene_hit :516-551: triangle record from (slot, t, u, v), then the spheres ----
         bool hit_any = false;
         F3 hp = mk(0, 0, 0), hn = mk(0, 0, 0);
@@ -358,7 +271,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     if (need_shadow) {
                         ln.pend[12 * kPendStride] = end_after ? 1.0f : 0.0f; pend_put(ln, 3, nthr); pend_put(ln, 6, hp); pend_put(ln, 9, ndir);
                         ro = sh_o; rd = sh_d;
-                        start_ray(ST_TRAV_SHADOW, ST_SHADOW_DONE);
+                        launch = 2;
                     } else if (end_after) {
                         end_sample();
                     } else {
@@ -369,21 +282,117 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                 }
             }
         }
-    } else if (state == ST_SHADOW_DONE) {
-        // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
-        bool blocked = hit_slot >= 0;
-        if (!blocked || !ANYHIT) {
-            for (int i = 0; i < S.num_spheres; ++i) {
-                if (COUNT) c[C_SPHERE_TESTS]++;
-                float t_hit; F3 n_hit;
-                if (hit_sphere(S.spheres[i], ro, rd, closest, t_hit, n_hit)) { blocked = true; closest = t_hit; }
-            }
-        } else if (COUNT) {
-            c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
+    }
+    if (state == ST_BOUNCE) {
+        // top of the depth loop :727-744
+        bool go = depth < P.max_depth;
+        if (go && depth >= 5) {
+            float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+            p = fminf(p, 0.95f);
+            if (rand01(rng) > p) go = false;
+            else thr = thr * (1.0f / p);
         }
-        if (!blocked) L = L + pend_get(ln, 0);
-        if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
-        else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
+        if (!go) end_sample();
+        else launch = 1;
+    }
+    if (state == ST_GEN && sample >= ln.sample_end) {       // sample_end == spp with rng_mode 0
+        if constexpr (RNGMODE == 1) {
+            // this slice of the pixel's samples is done: its partial sum goes to the slice's own slot; dsrt_resolve_kernel
+            // adds the slices in order and tone-maps
+            float* dst = args.partial + ((size_t)out_index * (size_t)P.chunks + ln.chunk) * 3;
+            dst[0] = accum.x; dst[1] = accum.y; dst[2] = accum.z;
+        } else {
+            // tone map + store :1003-1030
+            float inv_spp = 1.0f / (float)spp;
+            F3 col = accum * inv_spp;
+            col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
+            col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
+            col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
+            col = clamp01(col);
+            const size_t o = (size_t)out_index * 3;
+            args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
+            args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
+            args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
+            if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
+        }
+        flush_counters<COUNT>(args, c);
+        state = ST_FETCH;
+    }
+    if (state == ST_FETCH) {
+        uint32_t item = atomicAdd(args.queue, 1u);
+        const uint32_t tt = (uint32_t)(P.tile * P.tile);
+        bool sliced = false;
+        if constexpr (RNGMODE == 1) {
+            // Only pixels of tiles that see geometry are cut into sample slices (slice fastest: a wave starts on few pixels);
+            // background tiles, which come last in the costliest-first order, stay one work item per pixel.
+            // *args.n_heavy = number of such tiles, written by the tile-order pre-pass (its own cache line: the queue word's
+            // line is busy with atomics).
+            const uint32_t heavy_pixels = *args.n_heavy * tt, heavy_items = heavy_pixels * (uint32_t)P.chunks;
+            sliced = item < heavy_items;
+            if (sliced) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }
+            else { ln.chunk = 0; item = item - heavy_items + heavy_pixels; }
+        }
+        if (item >= (uint32_t)P.local_tiles * tt) {
+            state = ST_DONE;
+        } else {
+            const uint32_t within = item % tt;
+            const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
+            const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
+            const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
+            const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;
+            const uint32_t in_x = (sub % per_row) * 8u + (l & 7u), in_y = (sub / per_row) * 8u + (l >> 3);
+            const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
+            if (x < W && row < H) {
+                px = x;
+                ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
+                out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
+                accum = mk(0, 0, 0);
+                if constexpr (RNGMODE == 0) {
+                    rng = (uint32_t)(px + ky * W) ^ P.seed32;   // :990
+                    sample = 0;
+                    ln.sample_end = spp;
+                } else {
+                    sample = sliced ? (int)ln.chunk * P.chunk_len : 0;
+                    ln.sample_end = sliced ? min(spp, sample + P.chunk_len) : spp;
+                    restream();
+                }
+                state = ST_GEN;
+            }
+        }
+    }
+    if (state == ST_GEN) {
+        {
+            float jx = ((float)sample + rand01(rng)) / (float)spp;          // :995-996
+            float jy = ((float)sample + rand01(rng)) / (float)spp;
+            float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
+            float v = ((float)ky + jy) / (float)(H - 1);
+            const F3 cam_o = ld3(P.cam_origin), cam_llc = ld3(P.cam_llc), cam_h = ld3(P.cam_horizontal), cam_v = ld3(P.cam_vertical);
+            ro = cam_o;
+            rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
+            depth = 0;
+            L = mk(0, 0, 0);
+            thr = mk(1, 1, 1);
+            if (COUNT) c[C_SAMPLES]++;
+            launch = 1;                                 // depth 0: no roulette, max_depth >= 1 (host guarantees)
+        }
+    }
+    // Ray start, shared by camera rays, bounces and shadow rays.  Mirrors the head of bvh_hit_closest :394-410: the root box is
+    // tested first; a miss means the BVH contributes nothing and the lane goes straight on to the state that consumes the result.
+    if (launch) {
+        if (COUNT) c[C_RAYS]++;
+        rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        closest = kTMax;
+        hit_slot = -1;
+        sp = 0;
+        steps = 0;
+        state = ST_SHADE - 1 + launch;                 // ST_SHADE for a closest-hit ray, ST_SHADOW_DONE for a shadow ray
+        if (S.root_ref != kRefNone) {
+            if (COUNT) c[C_BOX_FETCHES]++;
+            float t_entry;
+            if (slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state = ST_TRAV_CLOSEST - 1 + launch; }
+        }
+        // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
+        if (state == ST_SHADE && S.num_spheres == 0) end_sample();
     }
     if constexpr (RNGMODE == 1) ln.rng = rng.n;
 }

@@ -33,9 +33,12 @@
 
 namespace dsrt {
 constexpr int kWavesPerBlock = 4;
+#ifndef DSRT_WAVES_ATTR
+#define DSRT_WAVES_ATTR
+#endif
 
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const RenderArgs args) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
 
@@ -59,12 +62,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         // ADVANCE phase
         // =====================================================================================
         for (int budget = 0; budget < args.advance_budget; ++budget) {
-            if (!__any(state < ST_TRAV_CLOSEST)) break;
+            if (!wave_any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             if (state < ST_TRAV_CLOSEST) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE>(ln, args, c, flags);
         }
 
-        if (__all(state == ST_DONE)) break;
+        if (wave_all(state == ST_DONE)) break;
 
         // =====================================================================================
         // TRAVERSE phase ("while-while"), written flat: per wave iteration every lane that is descending performs at most
@@ -78,32 +81,32 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
         // Leaving a phase is decided by accumulated waste, in lane-slots: every wave iteration spent here costs the lanes
         // that are waiting for the OTHER phase one slot each; switching costs the lanes that are busy HERE one pass of the
         // other phase.  Switch when the first exceeds the second (the ratios are the relative lengths of the phases' code).
+        // Invariant used for the votes below: a lane that is not walking a ray has cur == kRefNone, so "walking" and its
+        // refinements are single compares on `cur` (a vote on one compare is the compare's own mask, no extra VALU work).
         for (int wait_waste = 0;;) {
-            const bool walking = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
-            const int n_walk = __popcll(__ballot(walking));
+            const int n_walk = __popcll(wave_ballot(cur != kRefNone));
             if (n_walk == 0) break;
-            const int n_wait = __popcll(__ballot(state < ST_TRAV_CLOSEST));
+            const int n_wait = __popcll(wave_ballot(state < ST_TRAV_CLOSEST));
             if (wait_waste * 10 >= n_walk * args.min_walk_iters) break;
             int leaf_waste = 0;
 
             // ---------------- phase I: pops and internal nodes ----------------
             for (;;) {
-                const bool live = (unsigned)(state - ST_TRAV_CLOSEST) <= 1u;
-                const int n_desc = __popcll(__ballot(live && cur >= 0));
-                const int n_leaf = __popcll(__ballot(live && cur < 0));
+                const int n_desc = __popcll(wave_ballot((unsigned)cur < (unsigned)kRefNone));      // kRefPop or an internal node
+                const int n_leaf = __popcll(wave_ballot(cur < 0));
                 if (n_desc == 0 || leaf_waste * 10 >= n_desc * args.leaf_ratio4) break;
                 leaf_waste += n_leaf;
                 wait_waste += n_wait;
-                if (COUNT) { c[C_NODE_SLOTS]++; if (live && cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
+                if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
                 // bbox_hit(node, ray, t_min, closest) for a box already known to be hit (src/gpu_render.cu:422-424, 462-468)
-                if (live && cur == kRefPop) {
+                if (cur == kRefPop) {
                     if (sp == 0) { cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE); }
                     else {
                         --sp;
                         uint2 e = lds_stack[wave][sp < K ? sp : K][lane];
-                        if (__any(sp >= K)) {               // wave-uniform guard: keeps the common path a plain ds_read_b64
+                        if (wave_any(sp >= K)) {               // wave-uniform guard: keeps the common path a plain ds_read_b64
                             if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
                         }
                         if (closest > __uint_as_float(e.y)) cur = (int)e.x;
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                 }
 
                 // node visit: both child boxes from one 64-byte record
-                if (live && (unsigned)cur < (unsigned)kRefPop) {
+                if ((unsigned)cur < (unsigned)kRefPop) {
                     if (CHECKED && (cur >= S.num_pairs || ++steps > kStepCap)) {
                         flags |= cur >= S.num_pairs ? kFlagBadNodeRef : kFlagStepCap;
                         cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE);
@@ -123,6 +126,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         // Both boxes at once: every quantity below is a (left, right) pair in two adjacent registers, so the
                         // subtractions / multiplications are packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32: IEEE per component,
                         // same results as the scalar forms).  Record layout: q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x), q1 = y, q2 = z.
+                        // (Doing the swap of :305-307 by address -- six 8-byte loads at near/far offsets -- saves the twelve selects
+                        // but costs three more memory instructions per visit and was 11 % slower: profiles/r01/README.md.)
                         const v2f lox = {q0.x, q0.y}, hix = {q0.z, q0.w}, loy = {q1.x, q1.y}, hiy = {q1.z, q1.w}, loz = {q2.x, q2.y}, hiz = {q2.z, q2.w};
                         const v2f ax = (lox - ro.x) * rinv.x, bx = (hix - ro.x) * rinv.x;      // bbox_hit :303-304
                         const v2f ay = (loy - ro.y) * rinv.y, by = (hiy - ro.y) * rinv.y;
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                         // the far child goes to stack[sp]; written unconditionally (slot sp is above the top, slot K is a dump
                         // slot for sp >= K), the stack only grows when both children were hit
                         lds_stack[wave][sp < K ? sp : K][lane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
-                        if (__any(both && sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store
+                        if (wave_any(sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store
                             if (sp - K < args.spill_entries) {
                                 args.spill[(size_t)(sp - K) * args.spill_stride + glane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
                                 if (COUNT) c[C_STACK_SPILLS]++;
@@ -156,8 +161,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
             }
 
             // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
-            const bool at_leaf = ((unsigned)(state - ST_TRAV_CLOSEST) <= 1u) && cur < 0;
-            if (__any(at_leaf)) {
+            const bool at_leaf = cur < 0;
+            if (wave_any(at_leaf)) {
                 wait_waste += n_wait;
                 int first = 0, count = 0;
                 if (at_leaf) {
@@ -171,7 +176,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) dsrt_render_kernel(const 
                     if (COUNT) c[C_NODES_ENTERED]++;
                     cur = kRefPop;
                 }
-                for (int i = 0; __any(i < count); ++i) {
+                for (int i = 0; wave_any(i < count); ++i) {
                     if (COUNT) c[C_TRI_SLOTS]++;
                     if (i < count) {
                         const int slot = first + i;
@@ -270,7 +275,7 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
             }
         }
     }
-    const uint32_t n = (uint32_t)__popcll(__ballot(hit));
+    const uint32_t n = (uint32_t)__popcll(wave_ballot(hit));
     if (lane == 0 && n) atomicAdd(&cost[k], n);
 }
 
