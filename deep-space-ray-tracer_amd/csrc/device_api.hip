@@ -66,7 +66,7 @@ struct DevBuf {
 
 // The scene in traversal layout, owning its device memory.
 struct PackedScene {
-    DevBuf<float4> pairs, tri_isect, tri_shade, tri_uv, materials;
+    DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, materials;
     DevBuf<int2> big_leaves;
     DevBuf<GPUSphere> spheres;
     DevBuf<GPUTextureHeader> tex_headers;
@@ -128,11 +128,45 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
             }
         }
         if (stack_need > 64) { set_error("BVH needs a traversal stack deeper than the reference's 64 entries"); return DSRT_ERR_BVH_DEPTH; }
+        // Triangle storage: every leaf gets ceil(count / 2) pair records of its own, filled in tri_indices order.
+        const bool textured = h.num_textures > 0 && h.textures && h.texture_pool;
+        auto emit_leaf = [&](const GPUBVHNode& n) -> int {
+            const int first_pair = (int)(isect.size() / 5);
+            for (int i = 0; i < n.tri_count; i += 2) {
+                float q[2][9] = {{0}};
+                for (int w = 0; w < 2; ++w) {
+                    const bool real = i + w < n.tri_count;
+                    const int src = real ? h.tri_indices[n.tri_offset + i + w] : -1;
+                    float4 s0 = as_f4(0, 0, 0, 0), s1 = s0, s2 = as_f4(0, bits(0), bits(-1), bits(-1)), u0 = s0, u1 = s0;
+                    if (real) {
+                        const GPUTriangle& t = h.triangles[src];
+                        const float v[9] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z, t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+                        std::memcpy(q[w], v, sizeof v);
+                        s0 = as_f4(t.n0.x, t.n0.y, t.n0.z, t.n1.x);
+                        s1 = as_f4(t.n1.y, t.n1.z, t.n2.x, t.n2.y);
+                        s2 = as_f4(t.n2.z, bits(t.material_id), bits(t.albedo_tex), bits(src));
+                        u0 = as_f4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
+                        u1 = as_f4(t.uv2.x, t.uv2.y, 0.0f, 0.0f);
+                    }
+                    shade.push_back(s0); shade.push_back(s1); shade.push_back(s2);
+                    if (textured) { uv.push_back(u0); uv.push_back(u1); }
+                }
+                isect.push_back(as_f4(q[0][0], q[1][0], q[0][1], q[1][1]));
+                isect.push_back(as_f4(q[0][2], q[1][2], q[0][3], q[1][3]));
+                isect.push_back(as_f4(q[0][4], q[1][4], q[0][5], q[1][5]));
+                isect.push_back(as_f4(q[0][6], q[1][6], q[0][7], q[1][7]));
+                isect.push_back(as_f4(q[0][8], q[1][8], 0.0f, 0.0f));
+            }
+            return first_pair;
+        };
+        isect.reserve(((size_t)N / 2 + (size_t)M / 2 + 1) * 5);
+        shade.reserve(((size_t)N + (size_t)M / 2 + 2) * 3);
         auto ref_of = [&](int node) -> int {
             const GPUBVHNode& n = h.bvh_nodes[node];
             if (n.tri_count <= 0) return slot_of[node];
-            if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, n.tri_offset);
-            big.push_back(make_int2(n.tri_offset, n.tri_count));
+            const int first_pair = emit_leaf(n);
+            if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, first_pair);
+            big.push_back(make_int2(first_pair, n.tri_count));
             return make_leaf_ref(7, (int)big.size() - 1);
         };
         pairs.resize(order.size() * 4);
@@ -143,7 +177,8 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
             pairs[4 * s + 0] = as_f4(l.bbox_min.x, r.bbox_min.x, l.bbox_max.x, r.bbox_max.x);
             pairs[4 * s + 1] = as_f4(l.bbox_min.y, r.bbox_min.y, l.bbox_max.y, r.bbox_max.y);
             pairs[4 * s + 2] = as_f4(l.bbox_min.z, r.bbox_min.z, l.bbox_max.z, r.bbox_max.z);
-            pairs[4 * s + 3] = as_f4(bits(ref_of(n.left)), bits(ref_of(n.right)), bits(depth_of[s]), 0.0f);
+            const int ref_left = ref_of(n.left), ref_right = ref_of(n.right);          // in this order: leaf records follow the walk
+            pairs[4 * s + 3] = as_f4(bits(ref_left), bits(ref_right), bits(depth_of[s]), 0.0f);
         }
         const GPUBVHNode& root = h.bvh_nodes[0];
         v.root_lo[0] = root.bbox_min.x; v.root_lo[1] = root.bbox_min.y; v.root_lo[2] = root.bbox_min.z;
@@ -151,26 +186,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         v.root_ref = ref_of(0);
         v.stack_need = stack_need;
 
-        const bool textured = h.num_textures > 0 && h.textures && h.texture_pool;
-        isect.resize((size_t)N * 3);
-        shade.resize((size_t)N * 3);
-        if (textured) uv.resize((size_t)N * 2);
-        for (int j = 0; j < N; ++j) {
-            const int src = h.tri_indices[j];
-            const GPUTriangle& t = h.triangles[src];
-            const float e1x = t.v1.x - t.v0.x, e1y = t.v1.y - t.v0.y, e1z = t.v1.z - t.v0.z;
-            const float e2x = t.v2.x - t.v0.x, e2y = t.v2.y - t.v0.y, e2z = t.v2.z - t.v0.z;
-            isect[3 * (size_t)j + 0] = as_f4(t.v0.x, t.v0.y, t.v0.z, e1x);
-            isect[3 * (size_t)j + 1] = as_f4(e1y, e1z, e2x, e2y);
-            isect[3 * (size_t)j + 2] = as_f4(e2z, 0.0f, 0.0f, 0.0f);
-            shade[3 * (size_t)j + 0] = as_f4(t.n0.x, t.n0.y, t.n0.z, t.n1.x);
-            shade[3 * (size_t)j + 1] = as_f4(t.n1.y, t.n1.z, t.n2.x, t.n2.y);
-            shade[3 * (size_t)j + 2] = as_f4(t.n2.z, bits(t.material_id), bits(t.albedo_tex), bits(src));
-            if (textured) {
-                uv[2 * (size_t)j + 0] = as_f4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
-                uv[2 * (size_t)j + 1] = as_f4(t.uv2.x, t.uv2.y, 0.0f, 0.0f);
-            }
-        }
+        if (isect.size() / 5 > (size_t)(1 << 28)) { set_error("too many triangle pair records"); return DSRT_ERR_INVALID; }
     }
     mats.resize((size_t)h.num_materials * 3);
     for (int i = 0; i < h.num_materials; ++i) {
@@ -193,7 +209,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
 
     if (pairs.size() * sizeof(float4) > 0xFFFFFFFFull) { set_error("BVH too large: internal-node records exceed 4 GiB"); return DSRT_ERR_INVALID; }
     int rc;
-    if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_isect.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
+    if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_pairs.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
         (rc = out.tri_uv.upload(uv)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
     std::vector<GPUSphere> sph(h.spheres, h.spheres + h.num_spheres);
     if ((rc = out.spheres.upload(sph))) return rc;
@@ -203,10 +219,10 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
     } else { out.tex_headers.reset(); out.tex_pool.reset(); }
 
-    v.pairs = out.pairs.p; v.tri_isect = out.tri_isect.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
+    v.pairs = out.pairs.p; v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
     v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
     v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
-    v.num_pairs = (int)(pairs.size() / 4); v.num_tris = has_bvh ? N : 0; v.num_big_leaves = (int)big.size();
+    v.num_pairs = (int)(pairs.size() / 4); v.num_tri_pairs = (int)(isect.size() / 5); v.num_big_leaves = (int)big.size();
     v.num_materials = h.num_materials; v.num_spheres = h.num_spheres; v.num_lights = num_lights;
     v.num_textures = (int)out.tex_headers.n; v.tex_pool_floats = (int)out.tex_pool.n;
     out.camera = h.camera;

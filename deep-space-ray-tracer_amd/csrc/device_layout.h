@@ -13,15 +13,19 @@
 //                q2 = (L.lo.z, R.lo.z, L.hi.z, R.hi.z)   q3 = (left_ref, right_ref, depth, -) as int bits
 //              Records are in depth-first order (a left child sits right behind its parent).
 //   child ref  >= 0: index of an internal node in `pairs`
-//              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles starting at slot
-//                    `payload` of the leaf-ordered triangle arrays; code 7: payload indexes `big_leaves` {first, count}
-//                    (leaves of more than 7 triangles only arise from coincident centroids, builder :408-414).
-//   tri_isect  triangles permuted into leaf order (slot j = tri_indices[j]; the indirection is gone), 48 bytes:
-//                (v0.x, v0.y, v0.z, e1.x) (e1.y, e1.z, e2.x, e2.y) (e2.z, 0, 0, 0),  e1 = v1 - v0, e2 = v2 - v0 in float,
-//              exactly the differences hit_triangle_index forms per test (src/gpu_render.cu:336-337).
-//   tri_shade  same order, 48 bytes, read once per closest hit, not per candidate:
+//              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles whose first PAIR record is
+//                    `payload`; code 7: payload indexes `big_leaves` {first pair, count} (leaves of more than 7 triangles
+//                    only arise from coincident centroids, builder :408-414).
+//   tri_pairs  a leaf's triangles in leaf order (tri_indices order; the indirection is gone), TWO per 80-byte record and
+//              interleaved like the boxes, so Moller-Trumbore runs on packed fp32 pairs, two triangles per step:
+//                (v0x.A, v0x.B, v0y.A, v0y.B) (v0z.A, v0z.B, e1x.A, e1x.B) (e1y.A, e1y.B, e1z.A, e1z.B)
+//                (e2x.A, e2x.B, e2y.A, e2y.B) (e2z.A, e2z.B, -, -)        e1 = v1 - v0, e2 = v2 - v0 in float,
+//              exactly the differences hit_triangle_index forms per test (src/gpu_render.cu:336-337).  A leaf with an odd
+//              count ends in a half-empty record whose B triangle is all zeros (det = 0: rejected by the |det| test).
+//              "Slot" of a triangle = 2 * pair + (0 for A, 1 for B); slots of padding triangles are never hit.
+//   tri_shade  indexed by slot, 48 bytes, read once per closest hit, not per candidate:
 //                (n0.x, n0.y, n0.z, n1.x) (n1.y, n1.z, n2.x, n2.y) (n2.z, material_id, albedo_tex, original index)
-//   tri_uv     same order, 32 bytes, only allocated when the scene has textures: (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
+//   tri_uv     indexed by slot, 32 bytes, only allocated when the scene has textures: (uv0.xy, uv1.xy) (uv2.xy, 0, 0)
 //   materials  the reference's 48-byte record viewed as 3 x float4.
 //   spheres / texture headers / texture pool: unchanged (few, wave-uniform or rarely touched).
 #pragma once
@@ -44,7 +48,7 @@ inline int make_leaf_ref(int code, int payload) { return kLeafBit | (code << 28)
 
 struct DeviceScene {
     const float4* pairs;
-    const float4* tri_isect;
+    const float4* tri_pairs;
     const float4* tri_shade;
     const float4* tri_uv;
     const int2*   big_leaves;
@@ -52,7 +56,7 @@ struct DeviceScene {
     const GPUSphere* spheres;
     const GPUTextureHeader* tex_headers;
     const float*  tex_pool;
-    int   num_pairs, num_tris, num_big_leaves, num_materials;
+    int   num_pairs, num_tri_pairs, num_big_leaves, num_materials;
     int   num_spheres, num_lights, num_textures, tex_pool_floats;
     float root_lo[3];
     float root_hi[3];

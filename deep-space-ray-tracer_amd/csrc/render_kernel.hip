@@ -33,8 +33,9 @@
 
 namespace dsrt {
 constexpr int kWavesPerBlock = 4;
+// Register budget: 4 waves per SIMD (= 4 blocks per CU, which is also what the blocks' 31 KB of LDS allow).
 #ifndef DSRT_WAVES_ATTR
-#define DSRT_WAVES_ATTR
+#define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
@@ -172,35 +173,51 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
                         if (CHECKED && first >= S.num_big_leaves) { flags |= kFlagBadBigLeaf; first = 0; count = 0; }
                         else { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
                     }
-                    if (CHECKED && (first < 0 || first + count > S.num_tris || ++steps > kStepCap)) { flags |= kFlagBadTriSlot; count = 0; }
+                    if (CHECKED && (first < 0 || first + ((count + 1) >> 1) > S.num_tri_pairs || ++steps > kStepCap)) { flags |= kFlagBadTriSlot; count = 0; }
                     if (COUNT) c[C_NODES_ENTERED]++;
                     cur = kRefPop;
                 }
-                for (int i = 0; wave_any(i < count); ++i) {
-                    if (COUNT) c[C_TRI_SLOTS]++;
+                // Two triangles (one pair record) per step.  Every quantity is an (A, B) pair in adjacent registers; both
+                // tests are evaluated in full against the same `closest`, then applied in the reference's order: A first, and
+                // B against the `closest` A may have just lowered -- the reference's sequence of accepts, bit for bit.
+                for (int i = 0; wave_any(i < count); i += 2) {
+                    if (COUNT) c[C_TRI_SLOTS] += 2;
                     if (i < count) {
-                        const int slot = first + i;
-                        const float4* tp = S.tri_isect + (size_t)slot * 3;
-                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                        const int pair = first + (i >> 1);
+                        const float4* tp = S.tri_pairs + (size_t)pair * 5;
+                        const float4 f0 = tp[0], f1 = tp[1], f2 = tp[2], f3 = tp[3];
+                        const float2 f4 = *reinterpret_cast<const float2*>(tp + 4);
+                        const bool has_b = i + 1 < count;
                         if (COUNT) c[C_TRI_TESTS]++;
+                        const v2f v0x = {f0.x, f0.y}, v0y = {f0.z, f0.w}, v0z = {f1.x, f1.y};
+                        const v2f e1x = {f1.z, f1.w}, e1y = {f2.x, f2.y}, e1z = {f2.z, f2.w};
+                        const v2f e2x = {f3.x, f3.y}, e2y = {f3.z, f3.w}, e2z = {f4.x, f4.y};
                         // Moller-Trumbore :336-353, evaluated in full; the reference's early returns become one predicate.
                         // Each `if (x) return false` is kept as `!(x)` so that NaNs fall the same way.
-                        const F3 v0 = mk(a0.x, a0.y, a0.z), e1 = mk(a0.w, a1.x, a1.y), e2 = mk(a1.z, a1.w, a2.x);
-                        const F3 pvec = cross(rd, e2);
-                        const float det = dot(e1, pvec);
-                        const float inv_det = 1.0f / det;
-                        const F3 tvec = ro - v0;
-                        const float u = dot(tvec, pvec) * inv_det;
-                        const F3 qvec = cross(tvec, e1);
-                        const float v = dot(rd, qvec) * inv_det;
-                        const float t = dot(e2, qvec) * inv_det;
-                        const bool accept = !(fabsf(det) < 1e-8f) && !(u < 0.0f) && !(u > 1.0f) && !(v < 0.0f) && !(u + v > 1.0f) &&
-                                            !(t < kTMin) && !(t > closest);
-                        if (accept) {
-                            closest = t; hit_slot = slot; hit_u = u; hit_v = v;
+                        const v2f pvx = rd.y * e2z - rd.z * e2y, pvy = rd.z * e2x - rd.x * e2z, pvz = rd.x * e2y - rd.y * e2x;   // cross(rd, e2)
+                        const v2f det = (e1x * pvx + e1y * pvy) + e1z * pvz;
+                        const v2f inv_det = {1.0f / det.x, 1.0f / det.y};
+                        const v2f tvx = ro.x - v0x, tvy = ro.y - v0y, tvz = ro.z - v0z;
+                        const v2f u = ((tvx * pvx + tvy * pvy) + tvz * pvz) * inv_det;
+                        const v2f qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;          // cross(tvec, e1)
+                        const v2f v = ((rd.x * qvx + rd.y * qvy) + rd.z * qvz) * inv_det;
+                        const v2f t = ((e2x * qvx + e2y * qvy) + e2z * qvz) * inv_det;
+                        const v2f uv = u + v;
+                        const bool ok_a = !(fabsf(det.x) < 1e-8f) && !(u.x < 0.0f) && !(u.x > 1.0f) && !(v.x < 0.0f) && !(uv.x > 1.0f) && !(t.x < kTMin);
+                        const bool ok_b = !(fabsf(det.y) < 1e-8f) && !(u.y < 0.0f) && !(u.y > 1.0f) && !(v.y < 0.0f) && !(uv.y > 1.0f) && !(t.y < kTMin);
+                        bool stop = false;
+                        if (ok_a && !(t.x > closest)) {
+                            closest = t.x; hit_slot = pair * 2; hit_u = u.x; hit_v = v.x;
                             if (COUNT) c[C_HIT_UPDATES]++;
-                            if (ANYHIT && state == ST_TRAV_SHADOW) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
+                            stop = ANYHIT && state == ST_TRAV_SHADOW;
                         }
+                        if (COUNT && has_b && !stop) c[C_TRI_TESTS]++;
+                        if (!stop && ok_b && !(t.y > closest)) {          // an absent B is all zeros: det == 0, never ok
+                            closest = t.y; hit_slot = pair * 2 + 1; hit_u = u.y; hit_v = v.y;
+                            if (COUNT) c[C_HIT_UPDATES]++;
+                            stop = ANYHIT && state == ST_TRAV_SHADOW;
+                        }
+                        if (stop) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
                     }
                 }
             }
@@ -256,9 +273,8 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
                     int first = leaf_payload(cur), count = leaf_code(cur) + 1;
                     if (count == 8) { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
                     for (int i = 0; i < count && !hit; ++i) {
-                        const float4* tp = S.tri_isect + (size_t)(first + i) * 3;
-                        const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                        const F3 v0 = mk(a0.x, a0.y, a0.z), e1 = mk(a0.w, a1.x, a1.y), e2 = mk(a1.z, a1.w, a2.x);
+                        const float* tp = reinterpret_cast<const float*>(S.tri_pairs + (size_t)(first + (i >> 1)) * 5) + (i & 1);
+                        const F3 v0 = mk(tp[0], tp[2], tp[4]), e1 = mk(tp[6], tp[8], tp[10]), e2 = mk(tp[12], tp[14], tp[16]);
                         const F3 pvec = cross(rd, e2);
                         const float det = dot(e1, pvec);
                         const float inv_det = 1.0f / det;
