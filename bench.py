@@ -188,7 +188,7 @@ def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, dep
             "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
             "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
-                                   f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode}}), flush=True)
+                                   f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode, "bvh": args.bvh}}), flush=True)
 
 
 def main():
@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--stack-entries", type=int, default=0)
     ap.add_argument("--sequence", action="store_true", help="config 5: render every pose of the file once (default 250 spp) and report frames/s")
     ap.add_argument("--rng-mode", type=int, default=0)
+    ap.add_argument("--bvh", choices=["median", "sah"], default="median",
+                    help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     args = ap.parse_args()
 
     import torch
@@ -246,7 +248,9 @@ def main():
             dist.barrier()
         mesh_name = f"procedural ISS-like stand-in (meshgen.py v{meshgen.VERSION}), target {args.tris} triangles"
     hs = d.HostScene().add_obj(obj)
-    hs.build_bvh()
+    hs.build_bvh(args.bvh)
+    if args.bvh != "median":
+        mesh_name += f" [NON-PARITY {args.bvh.upper()} BVH]"
     poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
 
     ctx = d.Context(local_rank)
@@ -332,8 +336,16 @@ def main():
             return {"frame": frame_idx, "sep_m": round(frx.sep_m, 1), "rng_mode": rng_mode, "kernel_ms": ms, "Msamples/s": W * H * spp / ms / 1e3,
                     "Mrays/s": sx.rays / ms / 1e3, "coverage": sx.primary_hits / max(1, sx.samples)}
         extras = {"note": "kernel-only times (HIP events), same mesh and size as the headline; rng_mode 1 = rocRAND-compatible Philox stream per "
-                          "(pixel, sample): statistically equivalent image, not bit-identical to the reference stream",
-                  "runs": [measure(0, 0), measure(args.frame, 1), measure(0, 1)]}
+                          "(pixel, sample): statistically equivalent image, not bit-identical to the reference stream; bvh sah = binned-SAH tree "
+                          "instead of the reference's median split (non-parity fast mode, SURVEY.md 8(f) n4)",
+                  "runs": [dict(measure(0, 0), bvh=args.bvh), dict(measure(args.frame, 1), bvh=args.bvh), dict(measure(0, 1), bvh=args.bvh)]}
+        if args.bvh == "median":
+            hs_sah = d.HostScene().add_obj(obj)
+            hs_sah.build_bvh("sah")
+            ctx.upload(hs_sah.view(cam, tuple(fr.sun_dir_model)))
+            extras["runs"] += [dict(measure(args.frame, 0), bvh="sah"), dict(measure(args.frame, 1), bvh="sah")]
+            ctx.upload(scene)                                       # back to the reference tree
+            del hs_sah
         ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
 
     if rank == 0:
@@ -356,7 +368,7 @@ def main():
                 "mesh_triangles": n_tris, "frame": args.frame, "width": W, "height": H, "spp": spp, "max_depth": depth,
                 "coverage": primary_hits / max(1.0, samples_counted), "rays_per_sample": rays / max(1.0, samples_counted),
                 "parallelism": f"screen tiles 8x8 interleaved over {n_gpus} GPU(s)" + (", one RCCL gather + de-interleave per step" if shard else ""),
-                "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
+                "bvh": args.bvh, "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
             },
             "roofline": {
                 "bound": "hbm",

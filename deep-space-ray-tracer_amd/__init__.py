@@ -74,8 +74,14 @@ class HostScene:
         self._built = False
         return self
 
-    def build_bvh(self):
-        _check(lib.dsrt_host_scene_build_bvh(self._h), "dsrt_host_scene_build_bvh")
+    def build_bvh(self, kind="median"):
+        """kind "median": the reference's tree (parity); "sah": binned-SAH tree, non-parity fast mode (include/dsrt.h)."""
+        if kind == "median":
+            _check(lib.dsrt_host_scene_build_bvh(self._h), "dsrt_host_scene_build_bvh")
+        elif kind == "sah":
+            _check(lib.dsrt_host_scene_build_bvh_sah(self._h), "dsrt_host_scene_build_bvh_sah")
+        else:
+            raise ValueError("build_bvh kind must be 'median' or 'sah'")
         self._built = True
         return self
 

@@ -435,7 +435,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.spill_entries = spill_entries;
     a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
-    a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 24;
+    a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off); the word 32 entries past

@@ -1,0 +1,150 @@
+// bvh_sah.cpp -- a surface-area-heuristic BVH over the same triangles, in the same node format as bvh_median.cpp.
+//
+// NOT the reference's tree.  The reference splits every range at the centroid median (src/gpu_scene_builder.cpp:343-459),
+// which is what bvh_median.cpp reproduces and what every parity statement about the reference is made on.  This builder is
+// the "non-parity fast mode" of SURVEY.md section 8(f) n4: a binned-SAH tree makes the same rays visit far fewer nodes on
+// a mesh of long thin members and large panels, but it changes which of two equal-distance hits is found last, and which
+// rays graze past a box in float arithmetic -- so a frame rendered on it is a statistically equivalent image, not the same
+// bytes.  (The kernel and the oracle both walk whatever tree the scene carries, so kernel-vs-oracle parity on this tree is
+// still exact and tests/test_gpu_parity.py checks it.)
+//
+// Top-down, 32 centroid bins per axis, all three axes tried, leaf at <= 4 triangles (the reference's leaf size);
+// nodes numbered in pre-order like the reference's, so the depth-first re-layout in device_api.hip sees the same shape.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "host_internal.hpp"
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void clear() { for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b.lo[a]); hi[a] = fmaxf(hi[a], b.hi[a]); } }
+    double half_area() const {
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kBins = 32;
+constexpr int kLeafMax = 4;
+
+struct SahBuilder {
+    const std::vector<Box>& tri_box;
+    const std::vector<float>& centroid;
+    std::vector<int>& order;
+    std::vector<GPUBVHNode>& nodes;
+    int height = 0;
+
+    int build(int start, int end, int level) {
+        const int self = (int)nodes.size();
+        nodes.emplace_back();
+        if (level > height) height = level;
+        Box box; box.clear();
+        Box cbox; cbox.clear();
+        for (int i = start; i < end; ++i) {
+            box.grow(tri_box[order[i]]);
+            for (int a = 0; a < 3; ++a) {
+                const float c = centroid[3 * (size_t)order[i] + a];
+                cbox.lo[a] = fminf(cbox.lo[a], c); cbox.hi[a] = fmaxf(cbox.hi[a], c);
+            }
+        }
+        {
+            GPUBVHNode& n = nodes[self];
+            n.bbox_min = DsrtF3{box.lo[0], box.lo[1], box.lo[2]};
+            n.bbox_max = DsrtF3{box.hi[0], box.hi[1], box.hi[2]};
+            n.left = n.right = -1;
+            n.tri_offset = start;
+            n.tri_count = end - start;
+        }
+        const int count = end - start;
+        if (count <= kLeafMax) return self;
+
+        // best binned split over the three axes
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            const float extent = cbox.hi[a] - cbox.lo[a];
+            if (!(extent > 0.0f)) continue;
+            Box bin_box[kBins]; int bin_n[kBins];
+            for (int b = 0; b < kBins; ++b) { bin_box[b].clear(); bin_n[b] = 0; }
+            const float scale = (float)kBins / extent;
+            for (int i = start; i < end; ++i) {
+                int b = (int)((centroid[3 * (size_t)order[i] + a] - cbox.lo[a]) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                bin_box[b].grow(tri_box[order[i]]);
+                bin_n[b]++;
+            }
+            double right_area[kBins]; int right_n[kBins];
+            Box acc; acc.clear(); int n = 0;
+            for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); n += bin_n[b]; right_area[b] = acc.half_area(); right_n[b] = n; }
+            acc.clear(); n = 0;
+            for (int b = 0; b + 1 < kBins; ++b) {
+                acc.grow(bin_box[b]); n += bin_n[b];
+                if (n == 0 || right_n[b + 1] == 0) continue;
+                const double cost = acc.half_area() * n + right_area[b + 1] * right_n[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) {
+            // every centroid coincides: nothing to sort by; split the range in half by position (keeps leaves small)
+            mid = (start + end) / 2;
+        } else {
+            const float lo = cbox.lo[best_axis], scale = (float)kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+            const float* c = centroid.data();
+            const int axis = best_axis, bin = best_bin;
+            auto it = std::partition(order.begin() + start, order.begin() + end, [=](int t) {
+                int b = (int)((c[3 * (size_t)t + axis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= bin;
+            });
+            mid = (int)(it - order.begin());
+            if (mid == start || mid == end) mid = (start + end) / 2;      // cannot happen with n > 0 on both sides; belt and braces
+        }
+        nodes[self].tri_offset = 0;
+        nodes[self].tri_count = 0;
+        const int l = build(start, mid, level + 1);
+        nodes[self].left = l;
+        const int r = build(mid, end, level + 1);
+        nodes[self].right = r;
+        return self;
+    }
+};
+
+}  // namespace
+
+extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
+    if (!hs) { dsrt::set_error("dsrt_host_scene_build_bvh_sah: null scene"); return DSRT_ERR_INVALID; }
+    hs->tri_indices.clear();
+    hs->nodes.clear();
+    hs->bvh_height = 0;
+    const size_t n = hs->tris.size();
+    if (n == 0) { hs->bvh_valid = true; return DSRT_OK; }
+    if (n > (size_t)1 << 28) { dsrt::set_error("more than 2^28 triangles"); return DSRT_ERR_INVALID; }
+    std::vector<Box> tri_box(n);
+    std::vector<float> centroid(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const GPUTriangle& t = hs->tris[i];
+        const float v[3][3] = {{t.v0.x, t.v1.x, t.v2.x}, {t.v0.y, t.v1.y, t.v2.y}, {t.v0.z, t.v1.z, t.v2.z}};
+        for (int a = 0; a < 3; ++a) {
+            tri_box[i].lo[a] = fminf(fminf(v[a][0], v[a][1]), v[a][2]);
+            tri_box[i].hi[a] = fmaxf(fmaxf(v[a][0], v[a][1]), v[a][2]);
+            centroid[3 * i + a] = 0.5f * (tri_box[i].lo[a] + tri_box[i].hi[a]);
+        }
+    }
+    hs->tri_indices.resize(n);
+    for (size_t i = 0; i < n; ++i) hs->tri_indices[i] = (int)i;
+    hs->nodes.reserve(n);
+    SahBuilder b{tri_box, centroid, hs->tri_indices, hs->nodes};
+    b.build(0, (int)n, 1);
+    hs->bvh_height = b.height;
+    hs->bvh_valid = true;
+    if (hs->bvh_height - 1 > 64) {
+        dsrt::set_error("SAH BVH needs a traversal stack deeper than 64 entries");
+        return DSRT_ERR_BVH_DEPTH;
+    }
+    return DSRT_OK;
+}

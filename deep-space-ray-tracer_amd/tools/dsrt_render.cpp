@@ -25,7 +25,8 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
-    int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1;
+    int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0;
+    bool sah = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* {
@@ -41,8 +42,11 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = std::atoi(next("--depth"));
         else if (a == "--frame") first = std::atoi(next("--frame"));
         else if (a == "--frames") count = std::atoi(next("--frames"));
+        else if (a == "--fast") { sah = true; rng_mode = 1; }      // non-parity fast mode: SAH tree + Philox stream per sample (include/dsrt.h)
+        else if (a == "--bvh") sah = std::string(next("--bvh")) == "sah";
+        else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -67,7 +71,7 @@ int main(int argc, char** argv) {
 
     DsrtHostScene* hs = dsrt_host_scene_create();
     if (dsrt_host_scene_add_obj(hs, obj.c_str(), 1.0) != DSRT_OK) return fail("loading the mesh");
-    if (dsrt_host_scene_build_bvh(hs) != DSRT_OK) return fail("building the BVH");
+    if ((sah ? dsrt_host_scene_build_bvh_sah(hs) : dsrt_host_scene_build_bvh(hs)) != DSRT_OK) return fail("building the BVH");
     GPUScene scene;
     if (dsrt_host_scene_view(hs, &scene) != DSRT_OK) return fail("viewing the scene");
     std::printf("mesh: %d triangles, %d BVH nodes, %d materials\n", scene.num_triangles, scene.num_bvh_nodes, scene.num_materials);
@@ -92,7 +96,7 @@ int main(int argc, char** argv) {
         } else if (dsrt_scene_set_camera_sun(ctx, &cam, fr.sun_dir_model) != DSRT_OK) return fail("updating the camera");
         DsrtRenderDesc d;
         std::memset(&d, 0, sizeof d);
-        d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337;
+        d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337; d.rng_mode = rng_mode;
         DsrtStats st;
         if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, &st) != DSRT_OK) return fail("rendering");
         char name[64];

@@ -62,6 +62,12 @@ int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int n
  * the widest centroid axis, pre-order node numbering (src/gpu_scene_builder.cpp:343-459). */
 int dsrt_host_scene_build_bvh(DsrtHostScene* hs);
 
+/* NOT the reference's tree: a binned surface-area-heuristic BVH in the same node format (leaf <= 4, pre-order), the
+ * "non-parity fast mode" of SURVEY.md 8(f) n4.  Rays visit far fewer nodes; the frame is a statistically equivalent image
+ * (ties between equal-distance hits and float grazing cases resolve differently), not the reference's bytes.  There is no
+ * reference interface this replaces -- the reference has one builder (src/gpu_scene_builder.cpp:343-459). */
+int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs);
+
 /* Fill `out` with HOST pointers into the scene's arrays (valid until the scene is modified or
  * destroyed).  Camera / params / sun fields of `out` are zeroed; set them with dsrt_scene_set_frame. */
 int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out);

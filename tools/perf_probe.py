@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--counters", action="store_true")
     ap.add_argument("--rng", type=int, default=0)
+    ap.add_argument("--bvh", type=str, default="median")
     ap.add_argument("--tune", type=str, default="0:0:0", help="comma list of min_walk:adv_budget:leaf_ratio4")
     a = ap.parse_args()
     import dsrt_amd as d
@@ -28,7 +29,7 @@ def main():
     if not os.path.exists(obj):
         meshgen.write_obj(meshgen.build_station(a.tris), obj)
     hs = d.HostScene().add_obj(obj)
-    hs.build_bvh()
+    hs.build_bvh(a.bvh)
     poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
     ctx = d.Context(0)
     up = False
@@ -46,7 +47,7 @@ def main():
             for _ in range(a.reps):
                 _, _, st = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, tune=tune, rng_mode=a.rng))
                 best = st.kernel_ms if best is None else min(best, st.kernel_ms)
-            rec = {"frame": fi, "sep_m": round(fr.sep_m, 1), "tris": hs.view().num_triangles, "WxHxspp": f"{W}x{H}x{spp}", "K": st.lds_stack_entries,
+            rec = {"frame": fi, "sep_m": round(fr.sep_m, 1), "tris": hs.view().num_triangles, "WxHxspp": f"{W}x{H}x{spp}", "K": st.lds_stack_entries, "bvh": a.bvh,
                    "rng_mode": a.rng, "tune": tune, "kernel_ms": round(best, 3), "Msamples_s": round(W * H * spp / best / 1e3, 1)}
             if a.counters:
                 _, _, sc = ctx.render_to_host(d.make_desc(W, H, spp, 50, stack_entries=K, collect_counters=1, tune=tune, rng_mode=a.rng))
