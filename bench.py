@@ -193,7 +193,7 @@ def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, dep
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
             "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
                                    f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode, "bvh": args.bvh,
-                       "frames_in_flight": K}}), flush=True)
+                       "frames_in_flight": K, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}), flush=True)
 
 
 def main():
@@ -214,10 +214,13 @@ def main():
     ap.add_argument("--stack-entries", type=int, default=0)
     ap.add_argument("--sequence", action="store_true", help="config 5: render every pose of the file once (default 250 spp) and report frames/s")
     ap.add_argument("--rng-mode", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=4, help="--sequence: frames in flight at once (separate streams and contexts)")
+    ap.add_argument("--inflight", type=int, default=16, help="--sequence: frames in flight at once (separate streams and contexts)")
     ap.add_argument("--bvh", choices=["median", "sah"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     args = ap.parse_args()
+    if args.sequence:
+        # one hardware queue per frame in flight (the HIP runtime maps streams onto 4 by default); must be set before HIP starts
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.inflight)))
 
     import torch
     import torch.distributed as dist

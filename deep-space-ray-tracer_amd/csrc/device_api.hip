@@ -27,7 +27,7 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, hipStream_t stream);
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, uint32_t* n_live, bool cull, hipStream_t stream);
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -438,16 +438,26 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
-    // costliest-first tile order for this camera (scheduling only; tune[3] == 1 switches it off); the word 32 entries past
-    // the cost array receives the number of tiles that see geometry
+    // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
+    // see dsrt_tile_cost_kernel).  tune[3] == 1 switches both off, == 2 keeps the order but culls nothing; counting builds never
+    // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
+    // tiles that see geometry and the number of tiles in the order.
     if (ctx->tile_cost.n < (size_t)t.mine + 64) { int rc = ctx->tile_cost.alloc((size_t)t.mine + 64); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine + 64); if (rc) return rc; }
     uint32_t* n_heavy = ctx->tile_cost.p + t.mine + 32;
+    uint32_t* n_live = ctx->tile_cost.p + t.mine + 48;
     a.n_heavy = n_heavy;
+    a.n_live = n_live;
     if (desc->tune[3] != 1 && t.mine > 0) {
-        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, n_heavy, stream));
+        const bool cull = desc->tune[3] != 2 && desc->collect_counters == 0;
+        if (cull) {                                             // culled pixels are never written: they are the zeros put here
+            HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));
+            if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
+        }
+        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, n_heavy, n_live, cull, stream));
         a.frame.tile_order = ctx->tile_order.p;
     } else {
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n_heavy, t.mine, 1, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n_live, t.mine, 1, stream));
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
@@ -473,6 +483,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
         stats->visits_depth_lt6 = cnt[C_VISITS_LT6]; stats->visits_depth_lt9 = cnt[C_VISITS_LT9]; stats->visits_depth_lt12 = cnt[C_VISITS_LT12];
+        uint32_t live = 0;
+        HIP_TRY(hipMemcpy(&live, n_live, sizeof live, hipMemcpyDeviceToHost));
+        stats->tiles_total = (uint64_t)t.mine; stats->tiles_culled = (uint64_t)t.mine - live;
         if (stats->device_flags) {
             char buf[96];
             std::snprintf(buf, sizeof buf, "render kernel raised status flags 0x%x", stats->device_flags);

@@ -89,6 +89,7 @@ struct RenderArgs {
     float*    out_f32;
     uint32_t* queue;           // [0] next work item
     const uint32_t* n_heavy;   // rng_mode 1: number of tiles (first in tile_order) whose pixels are handed out in sample slices
+    const uint32_t* n_live;    // number of tiles in tile_order: the shard's tiles minus those proven empty by the pre-pass
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
     float*    partial;         // rng_mode 1: [output pixel][chunk][3] partial sample sums

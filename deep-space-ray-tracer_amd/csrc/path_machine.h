@@ -332,7 +332,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             if (sliced) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }
             else { ln.chunk = 0; item = item - heavy_items + heavy_pixels; }
         }
-        if (item >= (uint32_t)P.local_tiles * tt) {
+        if (item >= *args.n_live * tt) {               // tiles the pre-pass proved empty are not in the order at all
             state = ST_DONE;
         } else {
             const uint32_t within = item % tt;

@@ -234,8 +234,51 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
 // kernel then hands tiles out costliest first, so the pixels that are 1000-sample serial chains start early and the
 // end of the frame is filled with background pixels instead of a long tail.  This changes only the ORDER in which
 // pixels are rendered, never a pixel's value (each pixel depends on nothing but its own coordinates and the scene).
+//
+// Empty tiles.  With `cull` set, a block whose sample footprint cannot reach the root box is left out of the order
+// altogether and its pixels keep the zeros the output was cleared to.  That is exact, not approximate: every sample of such
+// a pixel fails the root test of bvh_hit_closest (:394-410), ray_color returns black (:744-747), the sum is 0 and the tone
+// map of 0 is byte 0 -- whatever the pixel's random numbers were, and no other pixel reads them.  "Cannot reach" is decided
+// conservatively: the pyramid of rays through the block GROWN BY ONE PIXEL on every side (the jitter of :995-996 keeps a
+// sample inside its pixel, at most on its far edge after rounding) is tested in double precision against the eight corners
+// of the root box; a block is dropped only if one side plane of that pyramid has the whole box outside it, or the box is
+// behind the camera.  One pixel is 5e-4 of the image width; the float rounding of the reference's ray set-up and slab test
+// is 1e-7 relative, so a ray the reference would let into the root box is never culled.  Not applied when the scene has
+// spheres (they are tested outside the BVH, :527-548) and not in counting builds (their counters include these samples).
+// cost word: bit 31 = the tile has at least one block that is not provably empty; low bits = pixels that see geometry.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S, const FrameParams P, uint32_t* __restrict__ cost) {
+__device__ bool block_footprint_misses_root(const DeviceScene& S, const FrameParams& P, int x0, int ky0) {
+    const double o[3] = {P.cam_origin[0], P.cam_origin[1], P.cam_origin[2]};
+    const double ulo = (double)(x0 - 1) / (double)(P.width - 1), uhi = (double)(x0 + 9) / (double)(P.width - 1);
+    const double vlo = (double)(ky0 - 1) / (double)(P.height - 1), vhi = (double)(ky0 + 9) / (double)(P.height - 1);
+    const double us[4] = {ulo, uhi, uhi, ulo}, vs[4] = {vlo, vlo, vhi, vhi};
+    double dir[4][3], mid[3] = {0, 0, 0};
+    for (int c = 0; c < 4; ++c)
+        for (int a = 0; a < 3; ++a) {
+            dir[c][a] = ((double)P.cam_llc[a] + us[c] * (double)P.cam_horizontal[a] + vs[c] * (double)P.cam_vertical[a]) - o[a];
+            mid[a] += dir[c][a];
+        }
+    double rel[8][3];
+    for (int j = 0; j < 8; ++j)
+        for (int a = 0; a < 3; ++a) rel[j][a] = (double)((j >> a) & 1 ? S.root_hi[a] : S.root_lo[a]) - o[a];
+    bool behind = true;
+    for (int j = 0; j < 8; ++j) behind = behind && (mid[0] * rel[j][0] + mid[1] * rel[j][1] + mid[2] * rel[j][2] <= 0.0);
+    if (behind) return true;
+    for (int c = 0; c < 4; ++c) {
+        const double* a = dir[c];
+        const double* b = dir[(c + 1) & 3];
+        double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        const double s = n[0] * mid[0] + n[1] * mid[1] + n[2] * mid[2];          // orient the side plane: inside is positive
+        if (s == 0.0) continue;                                                   // degenerate pyramid: never cull on it
+        if (s < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        bool outside = true;
+        for (int j = 0; j < 8; ++j) outside = outside && (n[0] * rel[j][0] + n[1] * rel[j][1] + n[2] * rel[j][2] < 0.0);
+        if (outside) return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S, const FrameParams P, uint32_t* __restrict__ cost, int cull) {
     const uint32_t blocks_per_tile = (uint32_t)((P.tile >> 3) * (P.tile >> 3));
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -246,6 +289,13 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
     const int x = (int)(tx * (uint32_t)P.tile + (sub % per_row) * 8u + (lane & 7u));
     const int row = (int)(ty * (uint32_t)P.tile + (sub / per_row) * 8u + (lane >> 3));
     bool hit = false;
+    {
+        // wave-uniform: this 8x8 block's first column and its lowest kernel row (ky = H - 1 - row; the block's rows are row0..row0+7)
+        const int bx0 = (int)(tx * (uint32_t)P.tile + (sub % per_row) * 8u), brow0 = (int)(ty * (uint32_t)P.tile + (sub / per_row) * 8u);
+        const bool empty = cull && S.num_spheres == 0 && (S.root_ref == kRefNone || block_footprint_misses_root(S, P, bx0, P.height - 1 - (brow0 + 7)));
+        if (empty) return;
+        if (lane == 0) atomicOr(&cost[k], 0x80000000u);
+    }
     if (x < P.width && row < P.height) {
         const int ky = P.height - 1 - row;
         const float u = ((float)x + 0.5f) / (float)(P.width - 1), v = ((float)ky + 0.5f) / (float)(P.height - 1);
@@ -295,25 +345,28 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
     if (lane == 0 && n) atomicAdd(&cost[k], n);
 }
 
-// One block: counting sort of the shard's tiles by cost, costliest first (65 bins; order inside a bin does not matter).
-__global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile, uint32_t* __restrict__ n_heavy) {
+// One block: counting sort of the shard's live tiles by cost, costliest first (65 bins; order inside a bin does not matter).
+__global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile,
+                                                               uint32_t* __restrict__ n_heavy, uint32_t* __restrict__ n_live) {
     __shared__ uint32_t bins[65], cursor[65];
     const uint32_t full = (uint32_t)(tile * tile);
     for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&bins[64u - min(64u, cost[t] * 64u / full)], 1u);
+    for (int t = threadIdx.x; t < n; t += blockDim.x)
+        if (cost[t]) atomicAdd(&bins[64u - min(64u, (cost[t] & 0x7FFFFFFFu) * 64u / full)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } *n_heavy = (uint32_t)n - bins[64]; }
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } *n_heavy = acc - bins[64]; *n_live = acc; }
     __syncthreads();
-    for (int t = threadIdx.x; t < n; t += blockDim.x) order[atomicAdd(&cursor[64u - min(64u, cost[t] * 64u / full)], 1u)] = (uint32_t)t;
+    for (int t = threadIdx.x; t < n; t += blockDim.x)
+        if (cost[t]) order[atomicAdd(&cursor[64u - min(64u, (cost[t] & 0x7FFFFFFFu) * 64u / full)], 1u)] = (uint32_t)t;
 }
 
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, hipStream_t stream) {
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, uint32_t* n_live, bool cull, hipStream_t stream) {
     const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));
     hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost);
-    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, n_heavy);
+    hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost, cull ? 1 : 0);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, n_heavy, n_live);
     return hipGetLastError();
 }
 

@@ -141,7 +141,7 @@ using namespace dsrt;
 extern "C" {
 
 const char* dsrt_last_error(void) { return dsrt::g_last_error.c_str(); }
-int dsrt_abi_version(void) { return 1; }
+int dsrt_abi_version(void) { return 2; }
 
 DsrtHostScene* dsrt_host_scene_create(void) { return new DsrtHostScene(); }
 void dsrt_host_scene_destroy(DsrtHostScene* hs) { delete hs; }

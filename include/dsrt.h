@@ -143,8 +143,9 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
-    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, 1 = natural tile
-                                       order instead of costliest-first} (see device_layout.h); none of them changes a pixel */
+    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass: 1 = natural
+                                       tile order and no empty-tile culling, 2 = costliest-first order but no culling} (see
+                                       device_layout.h and dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 
 typedef struct DsrtStats {
@@ -161,6 +162,8 @@ typedef struct DsrtStats {
     uint64_t idle_at_leaf, idle_waiting, idle_done;
     /* node visits at BVH depth < 6 / 9 / 12 (root = 0) */
     uint64_t visits_depth_lt6, visits_depth_lt9, visits_depth_lt12;
+    /* tiles of this shard / tiles the pre-pass proved empty and left out (their pixels are exactly black) */
+    uint64_t tiles_total, tiles_culled;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of

@@ -274,3 +274,56 @@ def test_rng_mode1_is_deterministic_shard_invariant_and_statistically_mode0(dsrt
     gpu_ctx.deinterleave(dsrt.make_desc(W, H, spp, depth, shard_count=world), gathered.data_ptr(), image.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), m1)
+
+
+def test_empty_tile_culling_is_exact(dsrt, gpu_ctx, oracle):
+    """Tiles whose sample footprint (grown by a pixel) cannot reach the root box are skipped and left black.  The frame must be
+    the oracle's, byte for byte, with and without the culling; and the culling must actually remove tiles on a far view,
+    none when the camera sits inside the root box, and none when the scene has spheres."""
+    import torch
+    hs = load_world(dsrt, "station_3k")
+    uploaded = False
+    views = [((-0.7, 0.0, 260.0), (0.0, 0.0, 0.0), 200, 112, True),       # far: a small station in a black frame
+             ((60.0, 45.0, 120.0), (30.0, 10.0, 0.0), 157, 83, True),     # off-centre, ragged size
+             ((0.0, 0.0, 300.0), (250.0, 0.0, 0.0), 96, 64, True),        # station almost out of view at the image edge
+             ((0.5, 0.2, 0.3), (10.0, 0.0, 0.0), 96, 64, False)]          # camera inside the root box: nothing can be culled
+    for lookfrom, lookat, W, H, expect_culled in views:
+        cam = dsrt.camera_look_at(lookfrom, lookat, 40.0, W, H, 8, 12)
+        scene = hs.view(cam, SUN)
+        if not uploaded:
+            gpu_ctx.upload(scene)
+            uploaded = True
+        else:
+            gpu_ctx.set_camera_sun(cam, SUN)
+        want_rgb, want_f32, _ = oracle.render(scene, W, H)
+        rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 8, 12), want_f32=True)
+        rgb_all, f32_all, st_all = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 8, 12, tune=(0, 0, 0, 2)), want_f32=True)
+        assert st_all.tiles_culled == 0 and st.tiles_total == st_all.tiles_total == ((W + 7) // 8) * ((H + 7) // 8)
+        assert (st.tiles_culled > 0) == expect_culled, (lookfrom, st.tiles_culled)
+        assert np.array_equal(rgb, want_rgb) and np.array_equal(rgb_all, want_rgb), lookfrom
+        assert np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)) and np.array_equal(f32_all.view(np.uint32), want_f32.view(np.uint32))
+        # rng_mode 1 goes through the same pre-pass: culled or not, same bytes
+        m1, _, s1 = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 8, 12, rng_mode=1))
+        m1_all, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 8, 12, rng_mode=1, tune=(0, 0, 0, 2)))
+        assert np.array_equal(m1, m1_all) and s1.tiles_culled == st.tiles_culled
+        # sharded, compact output
+        world, tile = 3, 8
+        lay = dsrt.shard_layout(dsrt.make_desc(W, H, 8, 12, tile_size=tile, shard_count=world))
+        gathered = torch.full((world * lay["rgb8_bytes_padded"],), 77, dtype=torch.uint8, device="cuda")
+        for rank in range(world):
+            part = gathered[rank * lay["rgb8_bytes_padded"]:(rank + 1) * lay["rgb8_bytes_padded"]]
+            gpu_ctx.render(dsrt.make_desc(W, H, 8, 12, tile_size=tile, shard_rank=rank, shard_count=world), part.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+        image = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+        gpu_ctx.deinterleave(dsrt.make_desc(W, H, 8, 12, tile_size=tile, shard_count=world), gathered.data_ptr(), image.data_ptr(),
+                             stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), want_rgb), lookfrom
+    # spheres are tested outside the BVH: a scene that has any is never culled
+    hs2 = load_world(dsrt, "mixed")
+    cam = dsrt.camera_look_at((3.0, 6.0, 140.0), (0.0, 2.0, 0.0), 40.0, 96, 64, 4, 10)
+    scene = hs2.view(cam, SUN)
+    gpu_ctx.upload(scene)
+    want_rgb, _, _ = oracle.render(scene, 96, 64)
+    rgb, _, st = gpu_ctx.render_to_host(dsrt.make_desc(96, 64, 4, 10))
+    assert st.tiles_culled == 0 and np.array_equal(rgb, want_rgb)
