@@ -151,6 +151,11 @@ def write_ppm(path, rgb, width, height):
     _check(lib.dsrt_write_ppm(str(path).encode(), rgb.ctypes.data, int(width), int(height)), "dsrt_write_ppm")
 
 
+def write_png(path, rgb, width, height):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _check(lib.dsrt_write_png(str(path).encode(), rgb.ctypes.data, int(width), int(height)), "dsrt_write_png")
+
+
 def make_desc(width, height, spp, max_depth=50, gamma=2.0, seed=1337, tile_size=0, shard_rank=0, shard_count=0,
               collect_counters=0, checked=0, stack_entries=0, tune=(0, 0, 0, 0), rng_mode=0):
     d = DsrtRenderDesc()

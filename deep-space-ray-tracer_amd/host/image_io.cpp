@@ -195,3 +195,43 @@ extern "C" int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, i
     if (done != n) { dsrt::set_error(std::string("short write to ") + path); return DSRT_ERR_IO; }
     return DSRT_OK;
 }
+
+// PNG writer (8-bit RGB, filter 0, one zlib stream): the reference shells out to ImageMagick to turn its PPM into a PNG
+// (src/main.cpp:28-36); this is that step without the shell.
+extern "C" int dsrt_write_png(const char* path, const uint8_t* rgb, int width, int height) {
+    if (!path || !rgb || width <= 0 || height <= 0) { dsrt::set_error("dsrt_write_png: bad argument"); return DSRT_ERR_INVALID; }
+    const size_t row = (size_t)width * 3;
+    std::vector<uint8_t> raw((row + 1) * (size_t)height);
+    for (int y = 0; y < height; ++y) {
+        raw[(row + 1) * y] = 0;                                              // filter type: none
+        std::memcpy(&raw[(row + 1) * y + 1], rgb + row * y, row);
+    }
+    uLongf zn = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) { dsrt::set_error("dsrt_write_png: zlib failed"); return DSRT_ERR_IO; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { dsrt::set_error(std::string("cannot open ") + path + " for writing"); return DSRT_ERR_IO; }
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    bool ok = true;
+    auto chunk = [&](const char* type, const uint8_t* data, size_t n) {
+        uint8_t head[8];
+        be32(head, (uint32_t)n);
+        std::memcpy(head + 4, type, 4);
+        uLong crc = crc32(0L, head + 4, 4);
+        if (n) crc = crc32(crc, data, (uInt)n);
+        uint8_t tail[4];
+        be32(tail, (uint32_t)crc);
+        ok = ok && std::fwrite(head, 1, 8, f) == 8 && (n == 0 || std::fwrite(data, 1, n, f) == n) && std::fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    ok = std::fwrite(sig, 1, 8, f) == 8;
+    uint8_t ihdr[13];
+    be32(ihdr, (uint32_t)width); be32(ihdr + 4, (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;     // 8 bits, colour type 2 (RGB), deflate, adaptive filters, no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (size_t)zn);
+    chunk("IEND", nullptr, 0);
+    std::fclose(f);
+    if (!ok) { dsrt::set_error(std::string("short write to ") + path); return DSRT_ERR_IO; }
+    return DSRT_OK;
+}

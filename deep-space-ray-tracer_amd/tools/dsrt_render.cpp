@@ -26,7 +26,7 @@ static int fail(const char* what) {
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
     int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0;
-    bool sah = false;
+    bool sah = false, png = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* {
@@ -45,8 +45,9 @@ int main(int argc, char** argv) {
         else if (a == "--fast") { sah = true; rng_mode = 1; }      // non-parity fast mode: SAH tree + Philox stream per sample (include/dsrt.h)
         else if (a == "--bvh") sah = std::string(next("--bvh")) == "sah";
         else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
+        else if (a == "--png") png = true;                          // frames as PNG instead of PPM (the reference converts with ImageMagick)
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast] [--png]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -100,9 +101,9 @@ int main(int argc, char** argv) {
         DsrtStats st;
         if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, &st) != DSRT_OK) return fail("rendering");
         char name[64];
-        std::snprintf(name, sizeof name, "/frame_%04zu.ppm", i);
+        std::snprintf(name, sizeof name, png ? "/frame_%04zu.png" : "/frame_%04zu.ppm", i);
         const std::string path = out_dir + name;
-        if (dsrt_write_ppm(path.c_str(), fb.data(), width, height) != DSRT_OK) return fail("writing the frame");
+        if ((png ? dsrt_write_png(path.c_str(), fb.data(), width, height) : dsrt_write_ppm(path.c_str(), fb.data(), width, height)) != DSRT_OK) return fail("writing the frame");
         std::printf("  kernel %.3f ms (%.1f Msamples/s)\nSaved %s\n", st.kernel_ms, (double)width * height * spp / (st.kernel_ms * 1e3), path.c_str());
     }
     dsrt_ctx_destroy(ctx);

@@ -107,6 +107,8 @@ int dsrt_camera_look_at(GPUCamera* out, const float from[3], const float at[3], 
 
 /* P6 writer, as the tail of gpu_render_scene (src/gpu_render.cu:1099-1107). */
 int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, int height);
+/* 8-bit RGB PNG: what the reference obtains by shelling out to ImageMagick on the PPM (src/main.cpp:28-36). */
+int dsrt_write_png(const char* path, const uint8_t* rgb, int width, int height);
 
 /* ===================================================================================== */
 /* Device side.                                                                          */

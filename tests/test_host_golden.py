@@ -114,3 +114,26 @@ def test_ppm_writer(dsrt, tmp_path):
     out = tmp_path / "o.ppm"
     dsrt.write_ppm(out, rgb, 4, 3)
     assert out.read_bytes() == b"P6\n4 3\n255\n" + rgb.tobytes()
+
+
+def test_png_writer(dsrt, tmp_path):
+    import zlib
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    out = tmp_path / "o.png"
+    dsrt.write_png(out, rgb, 53, 37)
+    raw = out.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, kind = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (53, 37, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(37, 1 + 53 * 3)
+    assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(37, 53, 3), rgb)
+    with pytest.raises(RuntimeError):
+        dsrt.write_png(tmp_path / "no_such_dir" / "o.png", rgb, 53, 37)
