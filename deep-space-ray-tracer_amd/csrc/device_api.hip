@@ -27,7 +27,8 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, uint32_t* n_live, bool cull, hipStream_t stream);
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
+                             uint32_t resident_lanes, bool cull, hipStream_t stream);
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -247,7 +248,9 @@ struct DsrtContext {
 
 namespace {
 
-constexpr size_t kCtrlWords = 4 + 2 * (size_t)kNumCounters;
+constexpr size_t kQueueLightWord = 64;                       // the light queue's counter: its own cache line, past the counters
+constexpr size_t kCtrlWords = kQueueLightWord + 16;
+static_assert(4 + 2 * (size_t)kNumCounters <= kQueueLightWord, "counters overlap the second queue word");
 
 struct Tiling { int tile, tiles_x, tiles_y, total, mine, padded; };
 bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
@@ -412,6 +415,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.out_rgb8 = d_rgb8;
     a.out_f32 = d_f32;
     a.queue = ctx->ctrl.p;
+    a.queue_light = ctx->ctrl.p + kQueueLightWord;
     a.flags = ctx->ctrl.p + 1;
     a.counters = (uint64_t*)(ctx->ctrl.p + 4);
 
@@ -419,7 +423,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     const int K = 8;
     if (desc->stack_entries != 0 && desc->stack_entries != 8) { set_error("dsrt_render: stack_entries must be 0 or 8"); return DSRT_ERR_INVALID; }
     const int threads_per_block = 64 * kernel_waves_per_block();
-    int blocks = ctx->num_cus * 8;                                        // persistent; workgroups beyond the resident set find the queue empty
+    const int resident_blocks = ctx->num_cus * 4;                         // 4 waves per SIMD = 4 workgroups of 4 waves per CU (render_kernel.hip)
+    int blocks = resident_blocks;                                         // persistent: exactly the resident set
     {
         const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
         if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
@@ -443,21 +448,20 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
     // tiles that see geometry and the number of tiles in the order.
     if (ctx->tile_cost.n < (size_t)t.mine + 64) { int rc = ctx->tile_cost.alloc((size_t)t.mine + 64); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine + 64); if (rc) return rc; }
-    uint32_t* n_heavy = ctx->tile_cost.p + t.mine + 32;
-    uint32_t* n_live = ctx->tile_cost.p + t.mine + 48;
-    a.n_heavy = n_heavy;
-    a.n_live = n_live;
+    uint32_t* sched = ctx->tile_cost.p + t.mine + 32;       // {tiles that see geometry, tiles in the order, heavy lanes per wave}
+    a.sched = sched;
     if (desc->tune[3] != 1 && t.mine > 0) {
         const bool cull = desc->tune[3] != 2 && desc->collect_counters == 0;
         if (cull) {                                             // culled pixels are never written: they are the zeros put here
             HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));
             if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
         }
-        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, n_heavy, n_live, cull, stream));
+        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, sched, (uint32_t)f.chunks,
+                                  (uint32_t)blocks * (uint32_t)threads_per_block, cull, stream));
         a.frame.tile_order = ctx->tile_order.p;
     } else {
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n_heavy, t.mine, 1, stream));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n_live, t.mine, 1, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sched, t.mine, 2, stream));           // every tile in the heavy queue, natural order
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(sched + 2), 64, 1, stream));
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
@@ -484,7 +488,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
         stats->visits_depth_lt6 = cnt[C_VISITS_LT6]; stats->visits_depth_lt9 = cnt[C_VISITS_LT9]; stats->visits_depth_lt12 = cnt[C_VISITS_LT12];
         uint32_t live = 0;
-        HIP_TRY(hipMemcpy(&live, n_live, sizeof live, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&live, sched + 1, sizeof live, hipMemcpyDeviceToHost));
         stats->tiles_total = (uint64_t)t.mine; stats->tiles_culled = (uint64_t)t.mine - live;
         if (stats->device_flags) {
             char buf[96];

@@ -87,9 +87,12 @@ struct RenderArgs {
     FrameParams frame;
     uint8_t*  out_rgb8;
     float*    out_f32;
-    uint32_t* queue;           // [0] next work item
-    const uint32_t* n_heavy;   // rng_mode 1: number of tiles (first in tile_order) whose pixels are handed out in sample slices
-    const uint32_t* n_live;    // number of tiles in tile_order: the shard's tiles minus those proven empty by the pre-pass
+    uint32_t* queue;           // next work item of the HEAVY queue (pixels, or sample slices, of tiles that see geometry)
+    uint32_t* queue_light;     // next work item of the LIGHT queue (pixels of the other live tiles); its own cache line
+    const uint32_t* sched;     // written by the pre-pass, read-only during the render (path_machine.h, ST_FETCH):
+                               //   [0] n_heavy  tiles that see geometry (the first n_heavy entries of tile_order)
+                               //   [1] n_live   tiles in tile_order: the shard's tiles minus those proven empty
+                               //   [2] spread   lanes per wave (1..64) that serve the heavy queue first; the others start on the light one
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
     float*    partial;         // rng_mode 1: [output pixel][chunk][3] partial sample sums

@@ -30,6 +30,7 @@ struct Lane {
     uint32_t out_index = 0, rng = 0;             // rng: LCG state (rng_mode 0) or draws taken in the current sample (rng_mode 1)
     int sample_end = 0;                          // rng_mode 1: this work item covers samples [.., sample_end) of the pixel
     uint32_t chunk = 0;                          // rng_mode 1: which slice of the pixel's samples
+    uint32_t lane = 0;                           // lane number inside the wave (which queue it serves first)
     F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
     int cur = kRefNone, sp = 0, hit_slot = -1;
@@ -319,20 +320,31 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         state = ST_FETCH;
     }
     if (state == ST_FETCH) {
-        uint32_t item = atomicAdd(args.queue, 1u);
+        // Two queues.  HEAVY: the pixels of tiles that see geometry, costliest tile first -- with rng_mode 1 cut into sample slices,
+        // slice fastest, so a wave starts on few pixels.  LIGHT: the pixels of the remaining live tiles (they only see background, or
+        // graze the root box), one work item per pixel.  `spread` lanes of every wave serve the heavy queue first, the rest the
+        // light one first; a lane whose queue is empty moves to the other.  When there are more heavy items than resident lanes
+        // spread is 64 and this is plain costliest-first.  When there are fewer (a far frame; one rank of a multi-GPU job), heavy
+        // items are dealt out `spread` per wave over ALL resident waves instead of filling the first waves with 64 serial chains
+        // each and leaving the rest of the chip with nothing to interleave: a wave's run time grows with the number of long
+        // chains it holds, because lanes in different phases take turns.  Only the assignment of pixels to lanes changes.
         const uint32_t tt = (uint32_t)(P.tile * P.tile);
-        bool sliced = false;
-        if constexpr (RNGMODE == 1) {
-            // Only pixels of tiles that see geometry are cut into sample slices (slice fastest: a wave starts on few pixels);
-            // background tiles, which come last in the costliest-first order, stay one work item per pixel.
-            // *args.n_heavy = number of such tiles, written by the tile-order pre-pass (its own cache line: the queue word's
-            // line is busy with atomics).
-            const uint32_t heavy_pixels = *args.n_heavy * tt, heavy_items = heavy_pixels * (uint32_t)P.chunks;
-            sliced = item < heavy_items;
-            if (sliced) { ln.chunk = item % (uint32_t)P.chunks; item /= (uint32_t)P.chunks; }
-            else { ln.chunk = 0; item = item - heavy_items + heavy_pixels; }
+        const uint32_t n_heavy = args.sched[0], n_live = args.sched[1], spread = args.sched[2];
+        const uint32_t per_pixel = RNGMODE == 1 ? (uint32_t)P.chunks : 1u;
+        const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt;
+        bool heavy = ln.lane < spread;
+        uint32_t item;
+        if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);       // (uniform address per branch:
+        if (item >= (heavy ? heavy_items : light_items)) {                                              //  one atomic per wave)
+            heavy = !heavy;
+            if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);
         }
-        if (item >= *args.n_live * tt) {               // tiles the pre-pass proved empty are not in the order at all
+        const bool sliced = RNGMODE == 1 && heavy;
+        ln.chunk = 0;
+        const bool none = item >= (heavy ? heavy_items : light_items);
+        if (sliced) { ln.chunk = item % per_pixel; item /= per_pixel; }
+        if (!heavy) item += n_heavy * tt;                     // position in tile_order x pixels per tile
+        if (none) {
             state = ST_DONE;
         } else {
             const uint32_t within = item % tt;

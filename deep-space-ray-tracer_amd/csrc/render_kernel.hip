@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
     __shared__ float lds_pend[kPendWords][kPendStride];
     Lane ln;
     ln.pend = &lds_pend[0][threadIdx.x];
+    ln.lane = (uint32_t)lane;
     int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
     float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v; uint32_t& steps = ln.steps;
     F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
 
 // One block: counting sort of the shard's live tiles by cost, costliest first (65 bins; order inside a bin does not matter).
 __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile,
-                                                               uint32_t* __restrict__ n_heavy, uint32_t* __restrict__ n_live) {
+                                                               uint32_t* __restrict__ sched, uint32_t items_per_pixel, uint32_t resident_lanes) {
     __shared__ uint32_t bins[65], cursor[65];
     const uint32_t full = (uint32_t)(tile * tile);
     for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
@@ -355,18 +356,29 @@ __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* _
     for (int t = threadIdx.x; t < n; t += blockDim.x)
         if (cost[t]) atomicAdd(&bins[64u - min(64u, (cost[t] & 0x7FFFFFFFu) * 64u / full)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; } *n_heavy = acc - bins[64]; *n_live = acc; }
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 0; b < 65; ++b) { cursor[b] = acc; acc += bins[b]; }
+        const uint32_t n_heavy = acc - bins[64];
+        // lanes per wave that start on the heavy queue: all of them once the heavy items outnumber the resident lanes, otherwise
+        // just enough to deal the heavy items out over every resident wave (see ST_FETCH in path_machine.h)
+        const unsigned long long heavy_items = (unsigned long long)n_heavy * full * items_per_pixel;
+        uint32_t spread = 64;
+        if (heavy_items < resident_lanes) spread = (uint32_t)((heavy_items * 64ull + resident_lanes - 1) / resident_lanes);
+        sched[0] = n_heavy; sched[1] = acc; sched[2] = spread < 1 ? 1u : spread;
+    }
     __syncthreads();
     for (int t = threadIdx.x; t < n; t += blockDim.x)
         if (cost[t]) order[atomicAdd(&cursor[64u - min(64u, (cost[t] & 0x7FFFFFFFu) * 64u / full)], 1u)] = (uint32_t)t;
 }
 
-hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* n_heavy, uint32_t* n_live, bool cull, hipStream_t stream) {
+hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
+                             uint32_t resident_lanes, bool cull, hipStream_t stream) {
     const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));
     hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost, cull ? 1 : 0);
-    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, n_heavy, n_live);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, sched, items_per_pixel, resident_lanes);
     return hipGetLastError();
 }
 
