@@ -441,6 +441,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
+    a.helpers = (desc->tune[3] & 4) ? 0 : 1;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
@@ -450,8 +451,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     if (ctx->tile_cost.n < (size_t)t.mine + 64) { int rc = ctx->tile_cost.alloc((size_t)t.mine + 64); if (rc) return rc; rc = ctx->tile_order.alloc((size_t)t.mine + 64); if (rc) return rc; }
     uint32_t* sched = ctx->tile_cost.p + t.mine + 32;       // {tiles that see geometry, tiles in the order, heavy lanes per wave}
     a.sched = sched;
-    if (desc->tune[3] != 1 && t.mine > 0) {
-        const bool cull = desc->tune[3] != 2 && desc->collect_counters == 0;
+    if ((desc->tune[3] & 3) != 1 && t.mine > 0) {
+        const bool cull = (desc->tune[3] & 3) != 2 && desc->collect_counters == 0;
         if (cull) {                                             // culled pixels are never written: they are the zeros put here
             HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));
             if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));

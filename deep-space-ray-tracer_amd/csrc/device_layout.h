@@ -101,6 +101,7 @@ struct RenderArgs {
     int       spill_entries;
     int       min_walk_iters;  // x10: the traverse phase yields to ADVANCE once (waiting lane-slots wasted) >= this/10 * walking lanes
     int       advance_budget;  // state transitions per lane per advance phase
+    int       helpers;         // 1: idle lanes trace shadow rays for busy lanes of their wave (path_machine.h)
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
 };
 

@@ -17,10 +17,24 @@
 namespace dsrt {
 
 enum : int {
-    ST_FETCH = 0, ST_GEN = 1, ST_BOUNCE = 2, ST_SHADE = 3, ST_SHADOW_DONE = 4,                      // advance-phase states
+    ST_FETCH = 0, ST_GEN = 1, ST_BOUNCE = 2, ST_SHADE = 3, ST_SHADOW_DONE = 4, ST_ENDING = 5,       // advance-phase states
     ST_TRAV_CLOSEST = 8, ST_TRAV_SHADOW = 9,                                                         // traverse-phase states
-    ST_DONE = 16
+    ST_DONE = 16,                                                                                    // out of work: free to trace shadow rays for others
+    kParked = 32                                                                                     // added to an advance-phase state: waiting for a helper's answer
 };
+
+// Shadow rays by idle lanes.  A lane that is out of work (ST_DONE) does not leave: when a busy lane of its wave reaches a
+// Lambertian hit that needs a sun shadow ray (:800-836), the idle lane takes that ray and the busy lane goes straight on to its
+// next bounce, so the two walks of a bounce overlap instead of following each other.  Nothing about the arithmetic changes: the
+// shadow ray draws no random numbers; its contribution waits in the owner's LDS strip and is added to L before anything else
+// touches L (the next hit's terms, the end of the sample), i.e. in the reference's order; at most one delegated ray per path
+// is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
+// the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
+//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding;
+//              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`
+//   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
+//              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
+constexpr uint32_t kAwait = 1u << 8;
 
 constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps than this (guards against corrupt input)
 
@@ -30,7 +44,7 @@ struct Lane {
     uint32_t out_index = 0, rng = 0;             // rng: LCG state (rng_mode 0) or draws taken in the current sample (rng_mode 1)
     int sample_end = 0;                          // rng_mode 1: this work item covers samples [.., sample_end) of the pixel
     uint32_t chunk = 0;                          // rng_mode 1: which slice of the pixel's samples
-    uint32_t lane = 0;                           // lane number inside the wave (which queue it serves first)
+    uint32_t aux = 0;                            // lane number inside the wave + helper / await bits (see above)
     F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
     int cur = kRefNone, sp = 0, hit_slot = -1;
@@ -42,7 +56,7 @@ struct Lane {
 };
 
 constexpr int kPendStride = 256;                // = threads per block of the render kernel
-constexpr int kPendWords = 13;
+constexpr int kPendWords = 14;                  // 13 words of continuation + one row for the shadow-ray request table
 __device__ __forceinline__ void pend_put(const Lane& ln, int i, F3 v) { ln.pend[(i + 0) * kPendStride] = v.x; ln.pend[(i + 1) * kPendStride] = v.y; ln.pend[(i + 2) * kPendStride] = v.z; }
 __device__ __forceinline__ F3 pend_get(const Lane& ln, int i) { return mk(ln.pend[(i + 0) * kPendStride], ln.pend[(i + 1) * kPendStride], ln.pend[(i + 2) * kPendStride]); }
 
@@ -94,11 +108,22 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
 
     // ray_color's return and the accumulate in render_kernel: clamp the SAMPLE to [0,1] (:935), add (:999), next sample.
     auto end_sample = [&]() {
+        if (ln.aux & kAwait) { state = ST_ENDING; return; }     // L is not complete until the delegated shadow ray has answered
         accum = accum + clamp01(L);
         sample++;
         restream();
         state = ST_GEN;
     };
+    const uint32_t my_lane = ln.aux & 63u;
+    auto strip_of = [&](uint32_t other_lane) -> float* { return ln.pend + ((int)other_lane - (int)my_lane); };
+
+    // Join: a runnable lane with a delegated shadow ray has its answer (the kernel parks it otherwise): add the sun term now, before
+    // this step can touch L, exactly where the reference adds it (:816-834).
+    if (ln.aux & kAwait) {
+        if (ln.pend[12 * kPendStride] == 2.0f) L = L + pend_get(ln, 0);
+        ln.aux &= ~kAwait;
+    }
+    if (state == ST_ENDING) end_sample();
 
     int launch = 0;         // set by a block that leaves a new ray in (ro, rd): 1 = closest-hit ray, 2 = shadow ray
 
@@ -114,10 +139,21 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         } else if (COUNT) {
             c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
         }
-        if (!blocked) L = L + pend_get(ln, 0);
-        if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
-        else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
+        const uint32_t owner_plus1 = ln.aux >> 16;
+        if (owner_plus1) {                                    // traced for another lane: hand the answer over, be free again
+            strip_of(owner_plus1 - 1u)[12 * kPendStride] = blocked ? 1.0f : 2.0f;
+            ln.aux &= 0xFFFFu;
+            state = ST_DONE;
+        } else {
+            if (!blocked) L = L + pend_get(ln, 0);
+            if (ln.pend[12 * kPendStride] != 0.0f) end_sample();
+            else { thr = pend_get(ln, 3); ro = pend_get(ln, 6); rd = pend_get(ln, 9); depth++; state = ST_BOUNCE; }
+        }
     }
+    // idle lanes of this wave, counted where all lanes that entered this step are together again
+    const unsigned long long free_mask = args.helpers ? wave_ballot(state == ST_DONE) : 0ull;
+    const uint32_t n_free = (uint32_t)__popcll(free_mask);
+    bool delegated = false;
     if (state == ST_SHADE) {
         // ---- finish scene_hit :516-551: triangle record from (slot, t, u, v), then the spheres ----
         bool hit_any = false;
@@ -269,6 +305,19 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                             nthr = thr * (albedo * (spdf / pdf_val));
                         }
                     }
+                    if (need_shadow && n_free > 0) {
+                        // hand the shadow ray to an idle lane if there is one for this request (requests of this step, in lane order)
+                        const unsigned long long req = wave_ballot(true);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(req >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)req, 0u));
+                        if (rank < n_free) {
+                            ln.pend[13 * kPendStride + ((int)rank - (int)my_lane)] = __uint_as_float(my_lane);
+                            pend_put(ln, 3, sh_o); pend_put(ln, 6, sh_d);
+                            ln.pend[12 * kPendStride] = 0.0f;
+                            ln.aux |= kAwait;
+                            delegated = true;
+                            need_shadow = false;
+                        }
+                    }
                     if (need_shadow) {
                         ln.pend[12 * kPendStride] = end_after ? 1.0f : 0.0f; pend_put(ln, 3, nthr); pend_put(ln, 6, hp); pend_put(ln, 9, ndir);
                         ro = sh_o; rd = sh_d;
@@ -281,6 +330,21 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                         state = ST_BOUNCE;
                     }
                 }
+            }
+        }
+    }
+    if (n_free > 0) {
+        // the idle lanes pick up the shadow rays handed over in this step: the r-th idle lane serves the r-th request
+        const unsigned long long handed = wave_ballot(delegated);
+        if (handed != 0ull && state == ST_DONE) {
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
+            if (r < (uint32_t)__popcll(handed)) {
+                const uint32_t owner = __float_as_uint(ln.pend[13 * kPendStride + ((int)r - (int)my_lane)]);
+                const float* theirs = strip_of(owner);
+                ro = mk(theirs[3 * kPendStride], theirs[4 * kPendStride], theirs[5 * kPendStride]);
+                rd = mk(theirs[6 * kPendStride], theirs[7 * kPendStride], theirs[8 * kPendStride]);
+                ln.aux |= (owner + 1u) << 16;
+                launch = 2;
             }
         }
     }
@@ -332,7 +396,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const uint32_t n_heavy = args.sched[0], n_live = args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? (uint32_t)P.chunks : 1u;
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt;
-        bool heavy = ln.lane < spread;
+        bool heavy = (ln.aux & 63u) < spread;
         uint32_t item;
         if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);       // (uniform address per branch:
         if (item >= (heavy ? heavy_items : light_items)) {                                              //  one atomic per wave)

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
     __shared__ float lds_pend[kPendWords][kPendStride];
     Lane ln;
     ln.pend = &lds_pend[0][threadIdx.x];
-    ln.lane = (uint32_t)lane;
+    ln.aux = (uint32_t)lane;
     int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
     float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v; uint32_t& steps = ln.steps;
     F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
@@ -64,9 +64,18 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
         // ADVANCE phase
         // =====================================================================================
         for (int budget = 0; budget < args.advance_budget; ++budget) {
+            // lanes whose delegated shadow ray (path_machine.h) has not answered yet step aside; those whose answer came are back
+            if (wave_any((ln.aux & kAwait) != 0u)) {
+                if (ln.aux & kAwait) {
+                    const bool answered = ln.pend[12 * kPendStride] != 0.0f;
+                    if (state >= kParked) { if (answered) state -= kParked; }
+                    else if (state < ST_TRAV_CLOSEST && !answered) state += kParked;
+                }
+            }
             if (!wave_any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
-            if (state < ST_TRAV_CLOSEST) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE>(ln, args, c, flags);
+            // idle lanes go through the step too: that is where they pick up shadow rays
+            if (state < ST_TRAV_CLOSEST || state == ST_DONE) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE>(ln, args, c, flags);
         }
 
         if (wave_all(state == ST_DONE)) break;
