@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -403,6 +404,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     const size_t out_pixels = desc->shard_count > 1 ? (size_t)t.padded * t.tile * t.tile : (size_t)desc->width * desc->height;
     if (desc->rng_mode == 1) {
         // a pixel's samples are independent streams: split them into up to 16 work items per pixel
+        // 16 slices: with 32/64/128 the many short work items cost more in half-empty advance passes than the shorter tail saves
+        // (1080p x 1000, near frame: 1142 / 1177 / 1693 ms against 1139; profiles/r01/README.md)
         f.chunk_len = f.spp < 128 ? (f.spp + 7) / 8 : (f.spp + 15) / 16;
         if (f.chunk_len < 1) f.chunk_len = 1;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;

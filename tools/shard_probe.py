@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--bvh", type=str, default="median")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--tune", type=str, default="0:0:0:0")
+    ap.add_argument("--counters", action="store_true")
     a = ap.parse_args()
     import torch
     import dsrt_amd as d
@@ -48,10 +49,19 @@ def main():
             buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
             ctx.render(desc, buf.data_ptr(), stream=stream, want_stats=True)
             times.append(min(ctx.render(desc, buf.data_ptr(), stream=stream, want_stats=True).kernel_ms for _ in range(2)))
+        extra = {}
+        if a.counters:
+            desc = d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=a.rng, tile_size=a.tile, collect_counters=1,
+                               tune=tuple(int(v) for v in a.tune.split(":")))
+            sc = ctx.render(desc, buf.data_ptr(), stream=stream, want_stats=True)
+            extra = {"counting_ms": round(sc.kernel_ms, 1), "samples": sc.samples, "rays": sc.rays, "util_node": round(sc.internal_entered / max(1, sc.node_slots), 3),
+                     "util_adv": round(sc.adv_active / max(1, sc.adv_slots), 3),
+                     "node_idle_leaf_wait_done": [round(sc.idle_at_leaf / max(1, sc.node_slots), 3), round(sc.idle_waiting / max(1, sc.node_slots), 3), round(sc.idle_done / max(1, sc.node_slots), 3)],
+                     "wave_iters_node_tri_adv": [sc.node_slots // 64, sc.tri_slots // 64, sc.adv_slots // 64]}
         worst = max(times)
         base = worst if base is None else base
         print(json.dumps({"frame": a.frame, "rng_mode": a.rng, "bvh": a.bvh, "shards": n, "tune": a.tune, "ranks_timed": ranks, "kernel_ms": [round(t, 2) for t in times],
-                          "speedup_vs_1": round(base / worst, 2), "efficiency": round(base / worst / n, 3)}), flush=True)
+                          "speedup_vs_1": round(base / worst, 2), "efficiency": round(base / worst / n, 3), **extra}), flush=True)
 
 
 if __name__ == "__main__":
