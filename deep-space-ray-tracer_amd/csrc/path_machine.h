@@ -31,7 +31,8 @@ enum : int {
 // is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
 // the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
 //   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding;
-//              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`
+//              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`;
+//              bits 24-31: probe launch only: rays traced for the current pixel (saturating)
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
@@ -139,10 +140,10 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         } else if (COUNT) {
             c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
         }
-        const uint32_t owner_plus1 = ln.aux >> 16;
+        const uint32_t owner_plus1 = (ln.aux >> 16) & 0x7Fu;
         if (owner_plus1) {                                    // traced for another lane: hand the answer over, be free again
             strip_of(owner_plus1 - 1u)[12 * kPendStride] = blocked ? 1.0f : 2.0f;
-            ln.aux &= 0xFFFFu;
+            ln.aux &= 0xFF00FFFFu;
             state = ST_DONE;
         } else {
             if (!blocked) L = L + pend_get(ln, 0);
@@ -380,6 +381,11 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
             if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
         }
+        if (args.tile_work) {                                   // probe launch: what this pixel cost, added to its tile
+            const uint32_t g = (uint32_t)((H - 1 - ky) / P.tile) * (uint32_t)P.tiles_x + (uint32_t)(px / P.tile);
+            atomicAdd(&args.tile_work[g / (uint32_t)P.shard_count], ln.aux >> 24);
+            ln.aux &= 0x00FFFFFFu;
+        }
         flush_counters<COUNT>(args, c);
         state = ST_FETCH;
     }
@@ -456,6 +462,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     // tested first; a miss means the BVH contributes nothing and the lane goes straight on to the state that consumes the result.
     if (launch) {
         if (COUNT) c[C_RAYS]++;
+        if (args.tile_work && (ln.aux >> 24) < 255u) ln.aux += 1u << 24;
         rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
         closest = kTMax;
         hit_slot = -1;

@@ -381,6 +381,38 @@ __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* _
         if (cost[t]) order[atomicAdd(&cursor[64u - min(64u, (cost[t] & 0x7FFFFFFFu) * 64u / full)], 1u)] = (uint32_t)t;
 }
 
+// Refinement of the order by measured cost: a probe launch of the render kernel itself (a few samples per pixel, same state
+// machine) has left the number of rays it traced for every tile in `work`; the tiles that see geometry -- the first sched[0]
+// entries of `order` -- are re-sorted by it, most work first, so the pixels with the longest serial sample chains start at
+// once instead of wherever their tile's coverage count put them.  Scheduling only.
+__global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, uint32_t* __restrict__ tmp,
+                                                                 const uint32_t* __restrict__ sched) {
+    __shared__ uint32_t bins[256], cursor[256], wmax;
+    const uint32_t n = sched[0];
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
+    if (threadIdx.x == 0) wmax = 1u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) atomicMax(&wmax, work[order[i]]);
+    __syncthreads();
+    const uint32_t top = wmax;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        tmp[i] = order[i];
+        atomicAdd(&bins[255u - (uint32_t)((unsigned long long)work[order[i]] * 255ull / top)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < 256; ++b) { cursor[b] = acc; acc += bins[b]; } }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t t = tmp[i];
+        order[atomicAdd(&cursor[255u - (uint32_t)((unsigned long long)work[t] * 255ull / top)], 1u)] = t;
+    }
+}
+
+hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_tile_reorder_kernel, dim3(1), dim3(1024), 0, stream, work, order, tmp, sched);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
                              uint32_t resident_lanes, bool cull, hipStream_t stream) {
     const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));

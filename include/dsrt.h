@@ -145,9 +145,10 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
-    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass: 1 = natural
-                                       tile order and no empty-tile culling, 2 = costliest-first order but no culling} (see
-                                       device_layout.h and dsrt_tile_cost_kernel); none of them changes a pixel */
+    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass flags: low two
+                                       bits 1 = natural tile order and no empty-tile culling, 2 = costliest-first order but no culling;
+                                       +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order}
+                                       (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 
 typedef struct DsrtStats {

@@ -327,3 +327,20 @@ def test_empty_tile_culling_is_exact(dsrt, gpu_ctx, oracle):
     want_rgb, _, _ = oracle.render(scene, 96, 64)
     rgb, _, st = gpu_ctx.render_to_host(dsrt.make_desc(96, 64, 4, 10))
     assert st.tiles_culled == 0 and np.array_equal(rgb, want_rgb)
+
+
+def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
+    """Probe-refined tile order (active from 128 spp), shadow-ray helpers, culling, natural order: every combination gives the
+    oracle's bytes.  128 spp on a small image: most lanes are idle, so nearly every shadow ray is traced by a helper lane."""
+    hs, scene, W, H, _, depth = _scene(dsrt, "station_near")
+    W, H, spp = 96, 54, 128
+    cam = dsrt.camera_look_at((12.0, 9.0, 38.0), (0.0, 0.0, 0.0), 40.0, W, H, spp, depth)
+    scene = hs.view(cam, SUN)
+    want_rgb, want_f32, _ = oracle.render(scene, W, H)
+    gpu_ctx.upload(scene)
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14):
+        rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
+        assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
+    a, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
+    b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, 12)))
+    assert np.array_equal(a, b)
