@@ -378,6 +378,9 @@ def main():
                 "coverage": primary_hits / max(1.0, samples_counted), "rays_per_sample": rays / max(1.0, samples_counted),
                 "parallelism": f"screen tiles 8x8 interleaved over {n_gpus} GPU(s)" + (", one RCCL gather + de-interleave per step" if shard else ""),
                 "bvh": args.bvh, "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
+                "strong_scaling_note": "rng_mode 0 keeps the reference's ONE LCG stream per pixel, so a pixel is a serial chain of spp samples; the slowest "
+                                       "pixel of this frame needs about 0.4 s however many GPUs share the frame, which caps the speed-up near 2.5x "
+                                       "(DESIGN.md section 5 has the per-rank times for 1/2/4/8 ranks and the rng_mode 1 column that does scale)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -387,8 +390,8 @@ def main():
                 "frac": (my_bytes / (my_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if my_kernel_ms > 0 else None,
                 "traffic": traffic_from_profile(n_tris, args.frame, W, H, spp, depth, None if args.obj else meshgen.VERSION) if n_gpus == 1 else None,
                 "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms, "algorithmic_bytes_per_launch": my_bytes,
-                "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path, "
-                        "working set sits in L2/Infinity Cache (SURVEY.md H6), so a low HBM fraction is expected",
+                "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path; "
+                        "the formula charges every re-read of a node or triangle and those are served by L1/L2 (SURVEY.md H6), so frac can exceed 1; 'traffic' (bytes that left L2, PMC) is the HBM-side figure",
             },
         }
         if extras:

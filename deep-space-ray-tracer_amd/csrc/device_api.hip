@@ -22,6 +22,7 @@
 
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
 hipError_t launch_resolve(const float* partial, int chunks, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
@@ -469,16 +470,17 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
                                   (uint32_t)blocks * (uint32_t)threads_per_block, cull, stream));
         a.frame.tile_order = ctx->tile_order.p;
         // Probe: the render kernel itself at kProbeSpp samples per pixel (reference stream, output discarded: the frame overwrites
-        // it) measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.2 % only when a pixel is a
+        // it) measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.5 % only when a pixel is a
         // long chain; tune[3] bit 3 (value 8) switches it off.
-        constexpr int kProbeSpp = 2;          // 1, 2, 4 and 8 order the tiles equally well (1150 +- 10 ms against 1260 without)
+        constexpr int kProbeSpp = 4;          // x one pixel in four of the heavy tiles: 6 ms at 1080p.  Every pixel at 1, 2, 4 or 8 samples orders
+                                              // the tiles just as well (1150 +- 10 ms against 1260 without) but costs 27 ms in queue atomics.
         if (!(desc->tune[3] & 8) && desc->collect_counters == 0 && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
             pa.frame.spp = kProbeSpp; pa.frame.chunks = 1; pa.frame.chunk_len = kProbeSpp;
             pa.out_f32 = nullptr; pa.partial = nullptr; pa.counters = nullptr;
             pa.tile_work = ctx->tile_work.p;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
-            HIP_TRY(launch_render(pa, K, 0, blocks, false, false, true, stream));
+            HIP_TRY(launch_probe(pa, blocks, stream));
             HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, stream));
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
         }

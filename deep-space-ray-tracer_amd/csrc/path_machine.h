@@ -86,7 +86,7 @@ __device__ __forceinline__ typename RngOf<RNGMODE>::type make_rng(Lane& ln, cons
     }
 }
 
-template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
+template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
 __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, uint32_t* c, uint32_t& flags) {
     const DeviceScene& S = args.scene;
     const FrameParams& P = args.frame;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
             if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
         }
-        if (args.tile_work) {                                   // probe launch: what this pixel cost, added to its tile
+        if (PROBE) {                                            // probe launch: what this pixel cost, added to its tile
             const uint32_t g = (uint32_t)((H - 1 - ky) / P.tile) * (uint32_t)P.tiles_x + (uint32_t)(px / P.tile);
             atomicAdd(&args.tile_work[g / (uint32_t)P.shard_count], ln.aux >> 24);
             ln.aux &= 0x00FFFFFFu;
@@ -398,8 +398,10 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // items are dealt out `spread` per wave over ALL resident waves instead of filling the first waves with 64 serial chains
         // each and leaving the rest of the chip with nothing to interleave: a wave's run time grows with the number of long
         // chains it holds, because lanes in different phases take turns.  Only the assignment of pixels to lanes changes.
-        const uint32_t tt = (uint32_t)(P.tile * P.tile);
-        const uint32_t n_heavy = args.sched[0], n_live = args.sched[1], spread = args.sched[2];
+        // The probe visits one pixel in four (even column, even row) of the heavy tiles only: a tile's cost is wanted, and
+        // every work item costs one atomic on the queue word (about 13 ns each; 2 M of them are 27 ms at 1080p).
+        const uint32_t tt = PROBE ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
+        const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? (uint32_t)P.chunks : 1u;
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt;
         bool heavy = (ln.aux & 63u) < spread;
@@ -421,13 +423,15 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
             const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
-            const uint32_t sub = within >> 6, l = within & 63u, per_row = (uint32_t)P.tile >> 3;
-            const uint32_t in_x = (sub % per_row) * 8u + (l & 7u), in_y = (sub / per_row) * 8u + (l >> 3);
+            const uint32_t per_row = (uint32_t)P.tile >> 3;
+            const uint32_t sub = PROBE ? within >> 4 : within >> 6;                        // which 8x8 block of the tile
+            const uint32_t lx = PROBE ? (within & 3u) << 1 : within & 7u, ly = PROBE ? ((within >> 2) & 3u) << 1 : (within >> 3) & 7u;
+            const uint32_t in_x = (sub % per_row) * 8u + lx, in_y = (sub / per_row) * 8u + ly;
             const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
             if (x < W && row < H) {
                 px = x;
                 ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
-                out_index = P.compact_output ? (k * tt + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
+                out_index = P.compact_output ? (k * (uint32_t)(P.tile * P.tile) + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
                 accum = mk(0, 0, 0);
                 if constexpr (RNGMODE == 0) {
                     rng = (uint32_t)(px + ky * W) ^ P.seed32;   // :990
@@ -462,7 +466,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     // tested first; a miss means the BVH contributes nothing and the lane goes straight on to the state that consumes the result.
     if (launch) {
         if (COUNT) c[C_RAYS]++;
-        if (args.tile_work && (ln.aux >> 24) < 255u) ln.aux += 1u << 24;
+        if (PROBE && (ln.aux >> 24) < 255u) ln.aux += 1u << 24;
         rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
         closest = kTMax;
         hit_slot = -1;

@@ -38,8 +38,8 @@ constexpr int kWavesPerBlock = 4;
 #define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
+__device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
 
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
             if (!wave_any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
-            if (state < ST_TRAV_CLOSEST || state == ST_DONE) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE>(ln, args, c, flags);
+            if (state < ST_TRAV_CLOSEST || state == ST_DONE) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE>(ln, args, c, flags);
         }
 
         if (wave_all(state == ST_DONE)) break;
@@ -236,6 +236,17 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
 
     flush_counters<COUNT>(args, c);
     if (flags) atomicOr(args.flags, flags);
+}
+
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
+    render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false>(args);
+}
+
+// The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
+// tile's entry of args.tile_work.  Its own kernel symbol, so that profiles keep it apart from the frame's launch.
+__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_probe_kernel(const RenderArgs args) {
+    render_body<8, false, false, true, 0, true>(args);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -474,6 +485,11 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
     } else {
         hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE>), grid, block, 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_probe_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
     return hipGetLastError();
 }
 
