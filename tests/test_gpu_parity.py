@@ -397,3 +397,41 @@ def test_cli_renders_pose_frames_like_the_library(dsrt, oracle, tmp_path):
     assert abs(fast.astype(float).mean() - want.astype(float).mean()) < 3.0
     # usage errors
     assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+def test_randomised_cameras_sizes_and_switches_match_the_oracle(dsrt, gpu_ctx, oracle):
+    """A bounded fuzz over what the scheduling layers see: cameras near, far, inside and beside the station, ragged sizes, sample
+    counts on both sides of the probe threshold, depths, tile sizes, and random combinations of the scheduling switches.  The
+    expected image is always the oracle's, byte for byte (rng_mode 0), and rng_mode 1 must not depend on the switches."""
+    rng = np.random.default_rng(20251004)
+    worlds = {name: load_world(dsrt, name) for name in ("station_3k", "mixed", "textured")}
+    failures = []
+    for trial in range(36):
+        name = ("station_3k", "station_3k", "mixed", "textured")[trial % 4]
+        hs = worlds[name]
+        W, H = int(rng.integers(9, 140)), int(rng.integers(5, 90))
+        spp = int(rng.choice([1, 3, 8, 32, 128, 160]))
+        if W * H * spp > 400000:
+            spp = max(1, 400000 // (W * H))
+        depth = int(rng.choice([1, 2, 5, 12, 50]))
+        dist = float(rng.choice([0.3, 2.0, 15.0, 45.0, 200.0, 900.0]))
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        lookfrom = tuple(float(v) for v in direction * dist)
+        lookat = tuple(float(v) for v in rng.normal(size=3) * (0.0 if trial % 3 else dist * 0.4))
+        cam = dsrt.camera_look_at(lookfrom, lookat, float(rng.choice([20.0, 40.0, 75.0])), W, H, spp, depth)
+        sun = tuple(float(v) for v in rng.normal(size=3))
+        scene = hs.view(cam, sun)
+        want, want_f32, _ = oracle.render(scene, W, H)
+        gpu_ctx.upload(scene)
+        flags = int(rng.choice([0, 0, 2, 4, 8, 12, 6, 1]))
+        tile = int(rng.choice([0, 0, 16]))
+        rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tile_size=tile, tune=(0, 0, 0, flags)), want_f32=True)
+        if not (np.array_equal(rgb, want) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32))):
+            failures.append((trial, name, W, H, spp, depth, lookfrom, flags, tile, int((rgb != want).any(axis=2).sum())))
+        if trial % 6 == 0:
+            a, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
+            b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, 14)))
+            if not np.array_equal(a, b):
+                failures.append((trial, "rng_mode 1 depends on scheduling switches"))
+    assert not failures, failures
