@@ -141,7 +141,7 @@ def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, dep
     import torch.distributed as dist
     shard = world if world > 1 else 0
     K = max(1, args.inflight)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = dev.index if dev.index is not None else 0
     ctxs = [ctx]
     for _ in range(1, K):
         c = d.Context(local)
@@ -182,7 +182,7 @@ def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, dep
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -231,10 +231,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DSRT_BENCH_REHEARSAL=1: run the N-rank flow with every rank on GPU 0 and gloo carrying host copies -- a functional rehearsal of
+    # the multi-GPU path on a one-GPU box (timings mean nothing; rank 0 checks the reassembled image against a whole-frame render)
+    rehearsal = world > 1 and os.environ.get("DSRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, **kw)
     assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     n_gpus = world
     dev = torch.device("cuda", local_rank)
@@ -313,12 +330,17 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce(t, dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
     dt = timed(args.steps, args.warmup)
     my_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    rehearsal_report = None
+    if rehearsal and rank == 0:
+        whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
+        ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries), whole.data_ptr(), stream=stream, want_stats=True)
+        rehearsal_report = {"ranks_on_one_gpu": world, "backend": "gloo", "reassembled_image_equals_whole_frame_render": bool(torch.equal(whole, image))}
 
     # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the roofline ----
     cdesc = d.make_desc(W, H, spp, depth, shard_rank=desc.shard_rank, shard_count=desc.shard_count, collect_counters=1,
@@ -328,7 +350,7 @@ def main():
     my_bytes = algorithmic_bytes(st, pixels_mine)
     tot = torch.tensor([float(st.rays), float(st.primary_hits), float(st.samples), float(my_bytes)], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tot)
+        all_reduce(tot)
     rays, primary_hits, samples_counted, _ = [float(v) for v in tot.tolist()]
 
     # ---- extras (single GPU only): the far frame, and rng_mode 1 on both frames.  Reported, never the headline. ----
@@ -396,6 +418,8 @@ def main():
         }
         if extras:
             out["extras"] = extras
+        if rehearsal_report:
+            out["rehearsal"] = rehearsal_report
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget)
             if not args.no_extras:

@@ -60,6 +60,12 @@ def gather_to_root(part, world, rank, dst=0):
     import torch.distributed as dist
     if world == 1:
         return part
+    if part.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the N-rank flow on fewer GPUs than ranks (bench.py DSRT_BENCH_REHEARSAL): gloo carries host copies
+        host = part.cpu()
+        bucket = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+        dist.gather(host, bucket, dst=dst)
+        return torch.cat(bucket).to(part.device) if rank == dst else None
     bucket = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
     dist.gather(part, bucket, dst=dst)
     return torch.cat(bucket) if rank == dst else None

@@ -435,3 +435,24 @@ def test_randomised_cameras_sizes_and_switches_match_the_oracle(dsrt, gpu_ctx, o
             if not np.array_equal(a, b):
                 failures.append((trial, "rng_mode 1 depends on scheduling switches"))
     assert not failures, failures
+
+
+def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (tile shards, equal-sized compact buffers, one gather, de-interleave on rank 0, max-over-ranks
+    timing, JSON line) with two ranks sharing GPU 0 and gloo carrying host copies (DSRT_BENCH_REHEARSAL): rank 0 must
+    reassemble exactly the image a whole-frame render gives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSRT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--tris", "20000", "--width", "322", "--height", "190",
+           "--spp", "16", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "Msamples/s"
+    assert out["rehearsal"]["reassembled_image_equals_whole_frame_render"] is True
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0
