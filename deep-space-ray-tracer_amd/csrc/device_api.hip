@@ -211,7 +211,6 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         }
     }
 
-    if (pairs.size() * sizeof(float4) > 0xFFFFFFFFull) { set_error("BVH too large: internal-node records exceed 4 GiB"); return DSRT_ERR_INVALID; }
     int rc;
     if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_pairs.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
         (rc = out.tri_uv.upload(uv)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
