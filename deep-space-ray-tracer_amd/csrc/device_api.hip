@@ -399,6 +399,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     f.tile = t.tile; f.tiles_x = t.tiles_x; f.tiles_y = t.tiles_y;
     f.shard_rank = desc->shard_rank; f.shard_count = desc->shard_count > 1 ? desc->shard_count : 1;
     f.local_tiles = t.mine;
+    if ((unsigned long long)t.mine * (unsigned long long)(t.tile * t.tile) >= (1ull << 31)) { set_error("dsrt_render: image too large (2^31 pixels per shard)"); return DSRT_ERR_INVALID; }
     f.total_items = (uint32_t)t.mine * (uint32_t)(t.tile * t.tile);
     f.compact_output = desc->shard_count > 1 ? 1 : 0;
     f.chunks = 1; f.chunk_len = f.spp;
@@ -410,6 +411,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         f.chunk_len = f.spp < 128 ? (f.spp + 7) / 8 : (f.spp + 15) / 16;
         if (f.chunk_len < 1) f.chunk_len = 1;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
+        if ((unsigned long long)f.total_items * (unsigned long long)f.chunks >= (1ull << 32)) { set_error("dsrt_render: image too large for rng_mode 1 (more than 2^32 sample slices)"); return DSRT_ERR_INVALID; }
         f.total_items *= (uint32_t)f.chunks;
         const size_t words = out_pixels * (size_t)f.chunks * 3;
         if (ctx->partial.n < words) { int rc = ctx->partial.alloc(words); if (rc) return rc; }

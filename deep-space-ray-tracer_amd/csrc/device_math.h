@@ -52,8 +52,12 @@ struct PhiloxStream {
     uint32_t key0, key1;      // seed
     uint32_t sub0, sub1;      // sub-sequence = pixel * spp + sample
     uint32_t n;               // draws taken so far in this sub-sequence
+    // the 4-word block the last draw came from (one 10-round evaluation serves up to four consecutive draws); a scratch of
+    // the current advance step, not part of the stream's identity
+    uint32_t blk = 0xFFFFFFFFu, blk_sub0 = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 };
-__device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t which) {
+__device__ __forceinline__ void philox4x32_10_block(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0, uint32_t& o1,
+                                                    uint32_t& o2, uint32_t& o3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -62,10 +66,21 @@ __device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t k0, uint32_t k1,
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return which == 0 ? c0 : (which == 1 ? c1 : (which == 2 ? c2 : c3));
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t which) {
+    uint32_t o0, o1, o2, o3;
+    philox4x32_10_block(k0, k1, c0, c1, c2, c3, o0, o1, o2, o3);
+    return which == 0 ? o0 : (which == 1 ? o1 : (which == 2 ? o2 : o3));
 }
 __device__ __forceinline__ float rand01(PhiloxStream& g) {
-    const uint32_t w = philox4x32_10_word(g.key0, g.key1, g.n >> 2, 0u, g.sub0, g.sub1, g.n & 3u);
+    const uint32_t b = g.n >> 2;
+    if (b != g.blk || g.sub0 != g.blk_sub0) {                // (a sample's sub-sequences differ in their low word)
+        philox4x32_10_block(g.key0, g.key1, b, 0u, g.sub0, g.sub1, g.w0, g.w1, g.w2, g.w3);
+        g.blk = b; g.blk_sub0 = g.sub0;
+    }
+    const uint32_t which = g.n & 3u;
+    const uint32_t w = which == 0 ? g.w0 : (which == 1 ? g.w1 : (which == 2 ? g.w2 : g.w3));
     g.n++;
     return (float)(w & 0x00FFFFFFu) / 16777216.0f;
 }
