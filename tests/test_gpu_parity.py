@@ -456,3 +456,54 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "Msamples/s"
     assert out["rehearsal"]["reassembled_image_equals_whole_frame_render"] is True
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
+    """Every pixel of two production-size frames against the oracle (threads over row bands; the C call releases the GIL):
+    the near frame at 72 samples (probe-refined order, both queues, helpers in the tail) and a far frame at 16 (most tiles
+    culled, heavy items spread one or two per wave, nearly every shadow ray traced by an idle lane)."""
+    import threading
+    from dsrt_amd import meshgen
+    obj = tmp_path / "iss_60k.obj"
+    meshgen.generate(obj, 60000)
+    hs = dsrt.HostScene().add_obj(obj)
+    hs.build_bvh()
+    poses = dsrt.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
+    W, H = 1920, 1080
+    uploaded = False
+    for frame, spp in ((98, 72), (70, 16)):
+        fr = dsrt.pose_to_frame(poses[frame])
+        cam = dsrt.frame_camera(fr, 40.0, W, H, spp, 50)
+        scene = hs.view(cam, tuple(fr.sun_dir_model))
+        if uploaded:
+            gpu_ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+        else:
+            gpu_ctx.upload(scene)
+            uploaded = True
+        rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50), want_f32=True)
+        want = np.zeros((H, W, 3), np.uint8)
+        want32 = np.zeros((H, W, 3), np.float32)
+        n_threads = min(16, len(os.sched_getaffinity(0)))
+        edges = np.linspace(0, H, n_threads * 6 + 1).astype(int)
+        bands = list(zip(edges[:-1], edges[1:]))
+        lock = threading.Lock()
+
+        def worker():
+            while True:
+                with lock:
+                    if not bands:
+                        return
+                    y0, y1 = bands.pop()
+                part, part32, _ = oracle.render(scene, W, H, int(y0), int(y1))
+                r0, r1 = H - int(y1), H - int(y0)                    # kernel row y is image row H-1-y
+                want[r0:r1] = part[r0:r1]
+                want32[r0:r1] = part32[r0:r1]
+        threads = [threading.Thread(target=worker) for _ in range(n_threads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert np.array_equal(rgb, want), f"frame {frame}: {(rgb != want).any(axis=2).sum()} pixels differ"
+        assert np.array_equal(f32.view(np.uint32), want32.view(np.uint32)), frame
+        if frame == 70:
+            assert st.tiles_culled > 0.8 * st.tiles_total
