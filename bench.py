@@ -378,6 +378,25 @@ def main():
             ctx.upload(scene)                                       # back to the reference tree
             del hs_sah
         ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+        # two reference points for reading the numbers above: what this board's HBM does on a plain
+        # device-to-device copy, and the headline frame end to end into pinned host memory (render + 6 MB copy)
+        n_copy = 1 << 30
+        src, dst = torch.empty(n_copy, dtype=torch.uint8, device=dev), torch.empty(n_copy, dtype=torch.uint8, device=dev)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        extras["hbm_copy_GBps_measured"] = 8 * 2 * n_copy / (time.perf_counter() - t0) / 1e9
+        del src, dst
+        pinned = torch.empty(W * H * 3, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.render(desc, part.data_ptr(), stream=stream)
+        pinned.copy_(part[:W * H * 3], non_blocking=True)
+        torch.cuda.synchronize()
+        extras["frame_to_pinned_host_ms"] = (time.perf_counter() - t0) * 1e3
 
     if rank == 0:
         total_samples = W * H * spp
