@@ -475,7 +475,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         // long chain; tune[3] bit 3 (value 8) switches it off.
         constexpr int kProbeSpp = 4;          // x one pixel in four of the heavy tiles: 6 ms at 1080p.  Every pixel at 1, 2, 4 or 8 samples orders
                                               // the tiles just as well (1150 +- 10 ms against 1260 without) but costs 27 ms in queue atomics.
-        if (!(desc->tune[3] & 8) && desc->collect_counters == 0 && f.spp >= 64 * kProbeSpp) {
+        if (!(desc->tune[3] & 8) && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
             pa.frame.spp = kProbeSpp; pa.frame.chunks = 1; pa.frame.chunk_len = kProbeSpp;
             pa.out_f32 = nullptr; pa.partial = nullptr; pa.counters = nullptr;
