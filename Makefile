@@ -15,7 +15,7 @@ ARCH     ?= gfx950
 BUILD    := build
 
 HOST_SRC := $(PKG)/host/obj_mesh.cpp $(PKG)/host/image_io.cpp $(PKG)/host/scene_flatten.cpp $(PKG)/host/bvh_median.cpp $(PKG)/host/bvh_sah.cpp $(PKG)/host/pose_camera.cpp
-HIP_SRC  := $(PKG)/csrc/render_kernel.hip $(PKG)/csrc/device_api.hip
+HIP_SRC  := $(PKG)/csrc/render_kernel.hip $(PKG)/csrc/device_api.hip $(PKG)/csrc/microbench.hip $(PKG)/csrc/multi_gpu.hip
 HOST_OBJ := $(patsubst $(PKG)/host/%.cpp,$(BUILD)/host_%.o,$(HOST_SRC))
 HIP_OBJ  := $(patsubst $(PKG)/csrc/%.hip,$(BUILD)/hip_%.o,$(HIP_SRC))
 HEADERS  := $(wildcard include/*.h) $(wildcard $(PKG)/host/*.hpp) $(wildcard $(PKG)/csrc/*.h)
@@ -36,18 +36,21 @@ $(BUILD)/hip_%.o: $(PKG)/csrc/%.hip $(HEADERS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libdsrt_hip.so: $(HOST_OBJ) $(HIP_OBJ)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz -lrccl
 
-tools: $(PKG)/dsrt_render
+tools: $(PKG)/dsrt_render $(PKG)/main_flow_driver
 
 $(PKG)/dsrt_render: $(PKG)/tools/dsrt_render.cpp $(PKG)/libdsrt_hip.so $(HEADERS)
-	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -ldsrt_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -ldsrt_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
+
+$(PKG)/main_flow_driver: $(PKG)/tools/main_flow_driver.cpp $(PKG)/libdsrt_hip.so $(HEADERS)
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -ldsrt_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf $(BUILD) $(PKG)/libdsrt_hip.so $(PKG)/dsrt_render
+	rm -rf $(BUILD) $(PKG)/libdsrt_hip.so $(PKG)/dsrt_render $(PKG)/main_flow_driver
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib tools oracle clean

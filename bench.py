@@ -4,23 +4,41 @@
 
 A "step" is one complete render of the frame: every pixel, every sample, scene already resident in HBM in traversal layout
 (upload, BVH build and OBJ parsing are outside the timed region, as BASELINE.md section 3 prescribes; the reference redoes them per
-frame).  For N > 1 the image is sharded by interleaved 8x8 screen tiles (tile t -> rank t mod N), each rank renders its tiles
-into a compact buffer, one RCCL gather brings them to rank 0 and a small kernel restores image order -- all inside the step.
+frame -- their cost is reported in `setup`).  For N > 1 the image is sharded by interleaved 8x8 screen tiles (tile t -> rank t mod N),
+each rank renders its tiles into a compact buffer, one RCCL gather brings them to rank 0 and a small kernel restores image order -- all
+inside the step.  `--gpus N` without a torch.distributed launcher starts one (one rank per GPU) as a child process and exits with its
+code; `--single-process` instead drives the N GPUs from this one process through the library's own RCCL path (dsrt_multi_*).
 
 Mesh: the real ISS OBJ is not available, so unless --obj is given the procedural stand-in from
 deep-space-ray-tracer_amd/meshgen.py is generated (--tris, default 1,000,000 triangles).  Pose: --frame of the reference's
-rendezvous_1s_dt0_01s.txt (tests/golden/ copy).  The default frame is 98 (camera 35.7 m from the station, which fills the
-view); frame 0 (1787 m, ~0.04 % of the pixels see the station) is an RNG + ray-generation benchmark bounded by one pixel's
-serial LCG chain, and is reported in `extras` together with rng_mode 1 (skip with --no-extras).  Every figure carries the
-mesh, the frame and the primary-ray coverage.
+rendezvous_1s_dt0_01s.txt (tests/golden/ copy).  The default frame is 98 (camera 35.7 m from the station, which fills the view);
+frame 0 (1787 m, 99.9 % of the tiles provably empty and culled) is reported in `extras` as what it is: a culling rate.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1, `cpu_baseline`.
+
+roofline.  The path is branchy fp32 vector arithmetic over a scene that lives in L2 / Infinity Cache; the counters say it is bound
+by vector-ALU ISSUE (and, second, by the L1's request rate), not by HBM.  The object therefore carries
+  bound / achieved / peak / frac   the binding resource: VALU wave-instructions per second of the render kernel (PMC SQ_INSTS_VALU
+                                   of this very run, rocprofv3 child pass) against the chip's issue ceiling, 1 wave64 VALU
+                                   instruction per SIMD per 4 cycles (measured by the library's calibration kernel on this device:
+                                   tools/gather_sweep.py --valu, profiles/r02/)
+  l1                               16-byte L1 requests per second (PMC TCP_TOTAL_CACHE_ACCESSES) against the gather ceiling of the
+                                   calibration kernel run live (dsrt_microbench_gather: same launch shape, every lane gathering random
+                                   64-byte records as 4 x 16 B from an L2-resident table)
+  achieved_algorithmic, hbm        SURVEY.md section 8(d)'s algorithmic bytes per launch / kernel time (counts every re-read the caches
+                                   serve, so it is NOT bounded by the HBM peak), and the HBM-side figure: FETCH_SIZE / WRITE_SIZE of this
+                                   run (separate PMC passes, gfx950 read-side correction) / kernel time / 8 TB/s
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -28,6 +46,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_CYCLES_PER_WAVE_INSTR = 4.0   # measured: 4 waves/SIMD of independent v_fma chains issue one instruction per SIMD per 4.5 cycles (profiles/r02)
+RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0>"
 
 
 def algorithmic_bytes(st, pixels):
@@ -35,20 +55,6 @@ def algorithmic_bytes(st, pixels):
     with the counters of the kernel that was actually run (any-hit shadow rays included)."""
     return (24 * st.box_fetches + 16 * st.nodes_entered + 40 * st.tri_tests + 44 * st.hit_updates + 48 * st.shaded_hits +
             24 * st.sphere_tests + 12 * st.tex_fetches + 3 * pixels)
-
-
-def traffic_from_profile(n_tris, frame, W, H, spp, depth, mesh_version):
-    """HBM-side bytes per launch of the render kernel from the committed PMC profile (profiles/traffic_bench_default.json:
-    FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes, gfx950 read-side correction applied), if and only if it was
-    taken on this very workload; otherwise null."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_bench_default.json")))
-    except (OSError, ValueError):
-        return None
-    w = t.get("workload", {})
-    same = (w.get("mesh_triangles") == n_tris and w.get("frame") == frame and w.get("width") == W and w.get("height") == H and
-            w.get("spp") == spp and w.get("max_depth") == depth and w.get("rng_mode") == 0 and w.get("mesh_version") == mesh_version)
-    return t.get("hbm_bytes_corrected") if same else None
 
 
 def host_cores():
@@ -64,119 +70,170 @@ def host_cores():
 
 
 def cpu_baseline(d, scene, W, H, spp, budget_s):
-    """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: bands of rows around the image
-    centre at full spp, one row per thread per band, bands added until the time budget is used up."""
+    """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: single rows at full spp, spread evenly
+    over the whole image height (a stratified sample: centre rows alone would over-weight the station), one row per thread per round,
+    rounds added until the time budget is used up."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
     orc = Oracle()
     cores = host_cores()
+    order, step = [], H
+    seen = set()
+    while step >= 1:                                   # rows at H/2, then H/4 and 3H/4, ...: any prefix is spread over the image
+        for y in range(step // 2, H, max(1, step)):
+            if y not in seen:
+                seen.add(y)
+                order.append(y)
+        step //= 2
 
-    def band(y0):
-        cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in range(cores)]
-        jobs = [threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y0 + t, y0 + t + 1, None, None, cnt[t]))
-                for t in range(cores) if y0 + t < H]
+    def one_round(rows):
+        cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in rows]
+        jobs = [threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y, y + 1, None, None, cnt[i]))
+                for i, y in enumerate(rows)]
         for th in jobs:
             th.start()
         for th in jobs:
             th.join()
         return len(jobs)
 
-    rows, y = 0, max(0, H // 2 - cores)
+    rows, pos = 0, 0
     t0 = time.perf_counter()
-    while True:
-        rows += band(y)
-        y += cores
+    while pos < len(order):
+        rows += one_round(order[pos:pos + cores])
+        pos += cores
         dt = time.perf_counter() - t0
-        if dt >= budget_s or y >= H:
+        if dt >= budget_s:
             break
+    dt = time.perf_counter() - t0
     return {"value": rows * W * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{rows} rows starting at row {max(0, H // 2 - cores)} of the same frame at {W}x{H}x{spp} ({rows * W} pixels), {dt:.1f} s wall"}
+            "sample": f"{rows} full rows spread evenly over the image height (rows {sorted(order[:rows])[:3]}...), same frame at {W}x{H}x{spp} "
+                      f"({rows * W} pixels), {dt:.1f} s wall"}
 
 
-def book_baseline(obj_path, fr, cores):
+def book_baseline(obj_path, fr, cores, tsv_path=None):
     """The book-style CPU render BASELINE.json names: the reference's own hittable_list / sphere / triangle_mesh / material
     classes (compiled from /root/reference into oracle/_ref/book_render, prebuilt) under our book-style pixel loop.
-      * config C1 in full: the RTIOW three-sphere scene, 200x112 @ 16 spp, one process per core on disjoint row bands
-        (the classes draw from rand(), whose process-wide lock stops threads of one process from scaling);
+      * config C1 (RTIOW three-sphere scene): 200x112 @ 16 spp as configured, and a THREAD SWEEP at 800x448 @ 64 spp (22.9 M samples,
+        a run of seconds) over 1, 2, 4, ... cores written as `num_threads<TAB>duration_ns` (the schema of the reference's
+        scripts/performance.py:20-22); one process per core on disjoint row bands -- the classes draw from rand(), whose
+        process-wide lock stops threads of one process from scaling;
       * the ISS mesh: triangle_mesh::hit is a linear scan over all triangles, so a 24x14 @ 1 spp corner of the bench frame is
         timed on one core and the rate is quoted as measured (linear in samples)."""
-    import subprocess
     exe = os.path.join(ROOT, "oracle", "_ref", "book_render")
     if not os.path.exists(exe):
         return None
     assets = os.path.join(ROOT, "tests", "golden", "assets")
-    H = 112
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([exe, "c1_spheres.world", "200", str(H), "16", "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", "-",
-                               str(H * i // cores), str(H * (i + 1) // cores)], cwd=assets, stdout=subprocess.PIPE, text=True) for i in range(cores)]
-    outs = [json.loads(p.communicate(timeout=300)[0]) for p in procs]
-    wall = time.perf_counter() - t0
-    c1 = {"workload": "RTIOW 3 spheres + ground (tests/golden/assets/c1_spheres.world), 200x112 @ 16 spp, max_depth 50", "cores": cores,
-          "Msamples/s": sum(o["samples"] for o in outs) / max(o["seconds"] for o in outs) / 1e6, "wall_s": wall}
-    iss = None
+
+    def c1(W, H, spp, procs):
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen([exe, "c1_spheres.world", str(W), str(H), str(spp), "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", "-",
+                                str(H * i // procs), str(H * (i + 1) // procs)], cwd=assets, stdout=subprocess.PIPE, text=True) for i in range(procs)]
+        outs = [json.loads(p.communicate(timeout=600)[0]) for p in ps]
+        wall = time.perf_counter() - t0
+        return wall, sum(o["samples"] for o in outs), max(o["seconds"] for o in outs)
+
+    wall, samples, slowest = c1(200, 112, 16, cores)
+    out = {"kind": "reference classes + our book-style loop (oracle/book_render_driver.cpp)",
+           "c1": {"workload": "RTIOW 3 spheres + ground (tests/golden/assets/c1_spheres.world), 200x112 @ 16 spp, max_depth 50", "cores": cores,
+                  "Msamples/s": samples / slowest / 1e6, "wall_s": wall}}
+    sweep, n = [], 1
+    while n <= cores:
+        w, s, _ = c1(800, 448, 64, n)
+        sweep.append({"num_threads": n, "duration_ns": int(w * 1e9), "Msamples/s": s / w / 1e6})
+        n *= 2
+    out["c1_thread_sweep"] = {"workload": "same scene, 800x448 @ 64 spp, max_depth 50, one process per core", "rows": sweep}
+    if tsv_path:
+        try:
+            os.makedirs(os.path.dirname(tsv_path), exist_ok=True)
+            with open(tsv_path, "w") as f:
+                f.write("num_threads\tduration_ns\n")
+                for r in sweep:
+                    f.write(f"{r['num_threads']}\t{r['duration_ns']}\n")
+            out["c1_thread_sweep"]["tsv"] = os.path.relpath(tsv_path, ROOT)
+        except OSError:
+            pass
     try:
         world = f"/tmp/dsrt_book_{os.getpid()}.world"
         with open(world, "w") as f:
             f.write(f"obj {obj_path}\n")
         sun = [str(v) for v in fr.sun_dir_model]
         cam = [str(v) for v in fr.cam_in_model]
-        out = subprocess.run([exe, world, "24", "14", "1", "50", "1", *cam, "0", "0", "0", "40", *sun], stdout=subprocess.PIPE, text=True, timeout=240)
-        r = json.loads(out.stdout)
-        iss = {"workload": "bench mesh and pose, 24x14 @ 1 spp, max_depth 50 (triangle_mesh::hit scans every triangle per ray)", "cores": 1,
-               "Msamples/s": r["msamples_per_s"], "seconds": r["seconds"]}
+        res = subprocess.run([exe, world, "24", "14", "1", "50", "1", *cam, "0", "0", "0", "40", *sun], stdout=subprocess.PIPE, text=True, timeout=240)
+        r = json.loads(res.stdout)
+        out["iss_mesh"] = {"workload": "bench mesh and pose, 24x14 @ 1 spp, max_depth 50 (triangle_mesh::hit scans every triangle per ray)", "cores": 1,
+                           "Msamples/s": r["msamples_per_s"], "seconds": r["seconds"]}
         os.remove(world)
     except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported as such, it never stops the bench
-        iss = {"error": str(e)[:200]}
-    return {"kind": "reference classes + our book-style loop (oracle/book_render_driver.cpp)", "c1": c1, "iss_mesh": iss}
+        out["iss_mesh"] = {"error": str(e)[:200]}
+    return out
 
 
-def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name):
-    """BASELINE.json configs[4]: the whole pose file as one job.  The scene stays resident; per frame only camera and sun
-    change (the reference rebuilds and re-uploads everything per frame, src/main.cpp:405).  `--inflight K` frames are in
-    flight at once, each on its own HIP stream with its own context (scene uploaded K times -- 0.13 GB each at 1 M triangles)
-    and its own device + pinned host image: with the reference's one-LCG-stream-per-pixel a far frame ends in a long tail of a
-    few 250-sample serial chains, and the next frames' workgroups fill the CUs that tail leaves idle.  Frame k's image is
-    copied out on its stream while the other streams render."""
+# ------------------------------------------------------------------------------------------------------------------
+# PMC counters of THIS workload, measured in this run: bench.py starts itself under rocprofv3 as a child process, one pass per
+# counter set (never combined with tracing; FETCH_SIZE and WRITE_SIZE in passes of their own, as the guide prescribes).
+# ------------------------------------------------------------------------------------------------------------------
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"],
+              ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]]
+
+
+def pmc_counters(workload_args, timeout_s=240):
+    """{counter: value} for the LAST dispatch of the production render kernel in a child run of this workload, or None."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out, base = {}, tempfile.mkdtemp(prefix="dsrt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for i, names in enumerate(PMC_PASSES):
+        d = os.path.join(base, f"p{i}")
+        cmd = [rocprof, "--pmc", *names, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", *workload_args]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        except (subprocess.SubprocessError, OSError):
+            continue
+        per_dispatch = {}
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Kernel_Name"].replace(" ", "").startswith("void" + RENDER_KERNEL.replace(" ", "")) or RENDER_KERNEL.replace(" ", "") in r["Kernel_Name"].replace(" ", ""):
+                    per_dispatch.setdefault(int(r["Dispatch_Id"]), {}).setdefault(r["Counter_Name"], 0.0)
+                    per_dispatch[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        if per_dispatch:
+            out.update(per_dispatch[max(per_dispatch)])
+    shutil.rmtree(base, ignore_errors=True)
+    return out or None
+
+
+def spawn_distributed(n):
+    """`--gpus N` from a plain interpreter: start the N-rank job (one process per GPU) as a child and exit with its code.  Nothing has
+    touched the GPU in this process yet (torch is not even imported)."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+
+
+def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name):
+    """BASELINE.json configs[4]: the whole pose file as one job (deep-space-ray-tracer_amd/sequence.py)."""
     import torch
     import torch.distributed as dist
-    shard = world if world > 1 else 0
-    K = max(1, args.inflight)
-    local = dev.index if dev.index is not None else 0
-    ctxs = [ctx]
-    for _ in range(1, K):
-        c = d.Context(local)
-        c.upload(frame_scene(args.frame)[2])
-        ctxs.append(c)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(1, K)]
-    lay = d.shard_layout(d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard))
-    parts = [torch.zeros(lay["rgb8_bytes_padded"] if shard else 1, dtype=torch.uint8, device=dev) for _ in range(K)]
-    images = [torch.zeros(W * H * 3, dtype=torch.uint8, device=dev) for _ in range(K)] if (rank == 0 or not shard) else None
-    host = [torch.empty(W * H * 3, dtype=torch.uint8).pin_memory() for _ in range(K)] if rank == 0 else None
+    from dsrt_amd import sequence
     frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
+    mine = sequence.frame_assignment(frames, rank, world, args.split)
+    shard = (rank, world, shard_mod.gather_to_root) if (world > 1 and args.split == "tiles") else None
+    pipe = sequence.FramePipeline(d, ctx, W, H, spp, depth, inflight=args.inflight, rng_mode=args.rng_mode, device=dev, shard=shard)
 
-    def render_frame(i, slot):
-        fr, cam, _ = frame_scene(i)
-        c, stream = ctxs[slot], streams[slot]
-        c.set_camera_sun(cam, tuple(fr.sun_dir_model))
-        desc = d.make_desc(W, H, spp, depth, shard_rank=rank if shard else 0, shard_count=shard, rng_mode=args.rng_mode)
-        with torch.cuda.stream(stream):                               # everything of this frame is ordered on its slot's stream
-            target = parts[slot] if shard else images[slot]
-            c.render(desc, target.data_ptr(), stream=stream.cuda_stream)
-            if shard:
-                flat = shard_mod.gather_to_root(parts[slot], world, rank)
-                if rank == 0:
-                    c.deinterleave(desc, flat.data_ptr(), images[slot].data_ptr(), stream=stream.cuda_stream)
-            if rank == 0:
-                host[slot].copy_(images[slot], non_blocking=True)
+    def go(ids):
+        for i in ids:
+            fr, cam, _ = frame_scene(i)
+            pipe.submit(i, cam, tuple(fr.sun_dir_model))
+        pipe.drain()
 
-    for k in range(K):
-        render_frame(frames[0], k)                                    # warm-up of every slot (not timed)
+    go([mine[0] if mine else frames[0]] * pipe.K)                     # warm-up of every slot (not timed)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for n, i in enumerate(frames):
-        render_frame(i, n % K)
+    go(mine)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -185,15 +242,19 @@ def run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, dep
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    pipe.close()
     if rank == 0:
         print(json.dumps({
             "metric": "frames/s (pose sequence, 1920x1080, scene resident, frames in flight on separate streams, images copied to pinned host memory)",
-            "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": K,
+            "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": pipe.K,
             "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
             "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
                                    f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode, "bvh": args.bvh,
-                       "frames_in_flight": K, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}), flush=True)
+                       "frames_in_flight": pipe.K, "split": args.split if world > 1 else "single GPU",
+                       "parallelism": ("poses dealt round-robin to ranks, no data-path collective" if args.split == "frames" else
+                                       "every frame sharded by 8x8 tiles over all ranks, one RCCL gather per frame") if world > 1 else "one GPU",
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}), flush=True)
 
 
 def main():
@@ -208,19 +269,27 @@ def main():
     ap.add_argument("--frame", type=int, default=98)
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--obj", type=str, default="")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (far frame 0; rng_mode 1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (far frame 0; rng_mode 1; SAH tree; drop-in entry point)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (roofline fields that need counters become null)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--stack-entries", type=int, default=0)
     ap.add_argument("--sequence", action="store_true", help="config 5: render every pose of the file once (default 250 spp) and report frames/s")
+    ap.add_argument("--split", choices=["frames", "tiles"], default="frames",
+                    help="--sequence on N > 1 GPUs: frames = poses dealt round-robin to ranks (default); tiles = every frame tile-sharded + gathered")
     ap.add_argument("--rng-mode", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=16, help="--sequence: frames in flight at once (separate streams and contexts)")
+    ap.add_argument("--inflight", type=int, default=16, help="--sequence: frames in flight at once per GPU (separate streams; contexts share the scene)")
     ap.add_argument("--bvh", choices=["median", "sah"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
+    ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.sequence:
-        # one hardware queue per frame in flight (the HIP runtime maps streams onto 4 by default); must be set before HIP starts
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.inflight)))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and not args.single_process and not args.pmc_child:
+        spawn_distributed(args.gpus)                                   # never returns
+    # one hardware queue per frame in flight (the HIP runtime maps streams onto 4 by default); must be set before HIP starts
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, args.inflight)))
 
     import torch
     import torch.distributed as dist
@@ -228,7 +297,6 @@ def main():
     from dsrt_amd import meshgen
     from dsrt_amd import dist as shard_mod
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DSRT_BENCH_REHEARSAL=1: run the N-rank flow with every rank on GPU 0 and gloo carrying host copies -- a functional rehearsal of
@@ -237,6 +305,8 @@ def main():
     if rehearsal:
         local_rank = 0
     if world > 1:
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if rehearsal:
@@ -252,16 +322,16 @@ def main():
             t.copy_(h)
         else:
             dist.all_reduce(t, **kw)
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    n_gpus = world
+    n_gpus = args.gpus if args.single_process else world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- scene: mesh -> flatten -> BVH (host), upload + re-layout (device).  Not timed. ----
+    # ---- scene: mesh -> flatten -> BVH (host), upload + re-layout (device).  Not in the timed region; reported in `setup`. ----
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     if args.sequence and spp == 1000:
         spp = 250                                   # BASELINE.json configs[4]
+    setup = {}
     if args.obj:
         obj, mesh_name = args.obj, os.path.basename(args.obj)
     else:
@@ -273,13 +343,15 @@ def main():
         if world > 1:
             dist.barrier()
         mesh_name = f"procedural ISS-like stand-in (meshgen.py v{meshgen.VERSION}), target {args.tris} triangles"
+    t0 = time.perf_counter()
     hs = d.HostScene().add_obj(obj)
+    setup["obj_parse_flatten_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     hs.build_bvh(args.bvh)
+    setup[f"bvh_build_{args.bvh}_host_s"] = time.perf_counter() - t0
     if args.bvh != "median":
         mesh_name += f" [NON-PARITY {args.bvh.upper()} BVH]"
     poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
-
-    ctx = d.Context(local_rank)
 
     def frame_scene(idx):
         fr = d.pose_to_frame(poses[idx])
@@ -287,11 +359,58 @@ def main():
         return fr, cam, hs.view(cam, tuple(fr.sun_dir_model))
 
     fr, cam, scene = frame_scene(args.frame)
-    ctx.upload(scene)
     n_tris = scene.num_triangles
 
+    if args.single_process and n_gpus > 1:
+        multi = d.Multi(list(range(n_gpus)), frames_in_flight=args.inflight if args.sequence else 1)
+        multi.upload(scene)
+        desc = d.make_desc(W, H, spp, depth, rng_mode=args.rng_mode)
+        if args.sequence:
+            frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
+            cams, suns = [], []
+            for i in frames:
+                f_i, c_i, _ = frame_scene(i)
+                cams.append(c_i)
+                suns.append(tuple(f_i.sun_dir_model))
+            multi.render_sequence(desc, cams[:n_gpus * args.inflight], suns[:n_gpus * args.inflight], want_images=False)      # warm-up
+            _, sec = multi.render_sequence(desc, cams, suns, want_images=False)
+            print(json.dumps({"metric": "frames/s (pose sequence, one host process, poses dealt round-robin to GPUs)", "value": len(frames) / sec, "unit": "frames/s",
+                              "n_gpus": n_gpus, "steps": len(frames), "warmup": n_gpus * args.inflight, "ms_per_step": sec / len(frames) * 1e3, "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"{mesh_name}: {n_tris} triangles, {len(frames)} poses, {W}x{H} @ {spp} spp, rng_mode {args.rng_mode}",
+                                         "parallelism": "dsrt_multi_render_sequence: frame i whole on GPU i mod N, no collective", "frames_in_flight": args.inflight}}), flush=True)
+            return
+        for _ in range(args.warmup):
+            multi.render_frame(desc, cam, tuple(fr.sun_dir_model))
+        t0 = time.perf_counter()
+        per_rank = []
+        for _ in range(args.steps):
+            _, ms, _ = multi.render_frame(desc, cam, tuple(fr.sun_dir_model))
+            per_rank.append(ms)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "Msamples/s (ISS-mesh frame, 1920x1080 @1000spp path-traced samples per second, whole job)", "value": W * H * spp * args.steps / dt / 1e6,
+                          "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"{mesh_name}: {n_tris} triangles, pose frame {args.frame}, {W}x{H} @ {spp} spp, max_depth {depth}, rng_mode {args.rng_mode}",
+                                     "parallelism": f"one host process, dsrt_multi_render_frame: 8x8 tiles interleaved over {n_gpus} GPUs, ncclGather to GPU 0 (RCCL: {multi.uses_rccl}), "
+                                                    "image copied to host inside the step", "kernel_ms_per_rank_last_step": per_rank[-1]}}), flush=True)
+        return
+
+    ctx = d.Context(local_rank)
+    t0 = time.perf_counter()
+    ctx.upload(scene)
+    torch.cuda.synchronize()
+    setup["pack_and_upload_s"] = time.perf_counter() - t0
+
+    if args.pmc_child:                               # the run rocprofv3 watches: this workload's kernel, twice, nothing else
+        part = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
+        dsc = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, rng_mode=args.rng_mode)
+        ctx.render(dsc, part.data_ptr(), stream=stream, want_stats=True)
+        ctx.render(dsc, part.data_ptr(), stream=stream, want_stats=True)
+        return
+
     if args.sequence:
-        run_sequence(args, d, ctx, hs, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
+        run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -303,12 +422,13 @@ def main():
     part = torch.zeros(lay["rgb8_bytes_padded"] if shard else W * H * 3, dtype=torch.uint8, device=dev)
     image = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev) if shard and rank == 0 else part
 
-    kernel_ms = []
+    kernel_ms, last_stats = [], []
 
     def step(collect=True):
         st = ctx.render(desc, part.data_ptr(), stream=stream, want_stats=True)
         if collect:
             kernel_ms.append(st.kernel_ms)
+            last_stats[:] = [st]
         if shard:
             flat = shard_mod.gather_to_root(part, world, rank)          # the one collective of the step (RCCL gather)
             if rank == 0:
@@ -336,13 +456,14 @@ def main():
 
     dt = timed(args.steps, args.warmup)
     my_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    tiles_total, tiles_culled = (last_stats[0].tiles_total, last_stats[0].tiles_culled) if last_stats else (0, 0)
     rehearsal_report = None
     if rehearsal and rank == 0:
         whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
         ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries), whole.data_ptr(), stream=stream, want_stats=True)
         rehearsal_report = {"ranks_on_one_gpu": world, "backend": "gloo", "reassembled_image_equals_whole_frame_render": bool(torch.equal(whole, image))}
 
-    # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the roofline ----
+    # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the algorithmic bytes ----
     cdesc = d.make_desc(W, H, spp, depth, shard_rank=desc.shard_rank, shard_count=desc.shard_count, collect_counters=1,
                         stack_entries=args.stack_entries)
     st = ctx.render(cdesc, part.data_ptr(), stream=stream, want_stats=True)
@@ -352,8 +473,11 @@ def main():
     if world > 1:
         all_reduce(tot)
     rays, primary_hits, samples_counted, _ = [float(v) for v in tot.tolist()]
+    lane_slots = {"node_loop_active": st.internal_entered / max(1, st.node_slots), "leaf_loop_active": st.tri_tests / max(1, st.tri_slots),
+                  "advance_active": st.adv_active / max(1, st.adv_slots), "node_loop_parked_at_leaf": st.idle_at_leaf / max(1, st.node_slots),
+                  "node_loop_waiting_for_advance": st.idle_waiting / max(1, st.node_slots), "node_loop_out_of_work": st.idle_done / max(1, st.node_slots)}
 
-    # ---- extras (single GPU only): the far frame, and rng_mode 1 on both frames.  Reported, never the headline. ----
+    # ---- extras (single GPU only).  Reported, never the headline. ----
     extras = None
     if not args.no_extras and world == 1:
         def measure(frame_idx, rng_mode):
@@ -361,23 +485,55 @@ def main():
             ctx.set_camera_sun(camx, tuple(frx.sun_dir_model))
             dx = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, rng_mode=rng_mode)
             ctx.render(dx, part.data_ptr(), stream=stream, want_stats=True)                       # warm-up
-            ms = min(ctx.render(dx, part.data_ptr(), stream=stream, want_stats=True).kernel_ms for _ in range(2))
+            runs = [ctx.render(dx, part.data_ptr(), stream=stream, want_stats=True) for _ in range(2)]
+            ms = min(r.kernel_ms for r in runs)
             cx = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, rng_mode=rng_mode, collect_counters=1)
             sx = ctx.render(cx, part.data_ptr(), stream=stream, want_stats=True)
-            return {"frame": frame_idx, "sep_m": round(frx.sep_m, 1), "rng_mode": rng_mode, "kernel_ms": ms, "Msamples/s": W * H * spp / ms / 1e3,
-                    "Mrays/s": sx.rays / ms / 1e3, "coverage": sx.primary_hits / max(1, sx.samples)}
+            culled = runs[0].tiles_culled / max(1, runs[0].tiles_total)
+            rec = {"frame": frame_idx, "sep_m": round(frx.sep_m, 1), "rng_mode": rng_mode, "kernel_ms": ms, "Mrays/s": sx.rays / ms / 1e3,
+                   "coverage": sx.primary_hits / max(1, sx.samples), "tiles_culled_frac": culled}
+            # a frame whose tiles are mostly culled is not sampled at this rate: the figure is (samples the image stands for) / time
+            rec["Msamples/s" if culled < 0.5 else "Msamples/s_nominal_(culling_rate:_most_tiles_are_proven_empty_and_never_sampled)"] = W * H * spp / ms / 1e3
+            return rec
         extras = {"note": "kernel-only times (HIP events), same mesh and size as the headline; rng_mode 1 = rocRAND-compatible Philox stream per "
                           "(pixel, sample): statistically equivalent image, not bit-identical to the reference stream; bvh sah = binned-SAH tree "
                           "instead of the reference's median split (non-parity fast mode, SURVEY.md 8(f) n4)",
                   "runs": [dict(measure(0, 0), bvh=args.bvh), dict(measure(args.frame, 1), bvh=args.bvh), dict(measure(0, 1), bvh=args.bvh)]}
         if args.bvh == "median":
             hs_sah = d.HostScene().add_obj(obj)
+            t0 = time.perf_counter()
             hs_sah.build_bvh("sah")
+            setup["bvh_build_sah_host_s"] = time.perf_counter() - t0
             ctx.upload(hs_sah.view(cam, tuple(fr.sun_dir_model)))
             extras["runs"] += [dict(measure(args.frame, 0), bvh="sah"), dict(measure(args.frame, 1), bvh="sah")]
             ctx.upload(scene)                                       # back to the reference tree
             del hs_sah
         ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+        # the reference's own three calls, end to end (src/main.cpp:405-428): build_gpu_scene (upload in the reference layouts) ->
+        # gpu_render_scene (scene fetched back, re-laid-out, uploaded, rendered, PPM written) -> free_gpu_scene; once cold, once warm
+        devs = d.GPUScene()
+        sun3 = (C.c_float * 3)(*fr.sun_dir_model)
+        cwd = os.getcwd()
+        tmpd = tempfile.mkdtemp(prefix="dsrt_dropin_", dir="/tmp")
+        os.chdir(tmpd)
+        try:
+            t0 = time.perf_counter()
+            rc = d.lib.dsrt_build_gpu_scene(hs._h, C.byref(cam), sun3, C.byref(devs))
+            torch.cuda.synchronize()
+            t_build = time.perf_counter() - t0
+            if rc == 0:
+                times = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    d.lib.gpu_render_scene(C.byref(devs), W, H)
+                    times.append((time.perf_counter() - t0) * 1e3)
+                extras["drop_in_gpu_render_scene"] = {"dsrt_build_gpu_scene_upload_ms": t_build * 1e3, "gpu_render_scene_first_call_ms": times[0],
+                                                      "gpu_render_scene_second_call_same_scene_ms": times[1], "wrote_ppm": os.path.exists("image_gpu.ppm"),
+                                                      "note": "whole call: scene check / re-layout, render of this frame, 6 MB copy-back, PPM write"}
+                d.lib.dsrt_free_gpu_scene(C.byref(devs))
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmpd, ignore_errors=True)
         # two reference points for reading the numbers above: what this board's HBM does on a plain
         # device-to-device copy, and the headline frame end to end into pinned host memory (render + 6 MB copy)
         n_copy = 1 << 30
@@ -398,6 +554,52 @@ def main():
         torch.cuda.synchronize()
         extras["frame_to_pinned_host_ms"] = (time.perf_counter() - t0) * 1e3
 
+    # ---- roofline: calibration kernels live, PMC counters of this workload from child passes ----
+    roof = None
+    if rank == 0:
+        secs = my_kernel_ms * 1e-3
+        roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms,
+                "achieved_algorithmic_GBps": my_bytes / secs / 1e9 if secs > 0 else None, "algorithmic_bytes_per_launch": my_bytes,
+                "note": "rank 0's launch. The kernel is bound by vector-ALU issue (one wave64 VALU instruction per SIMD per 4 cycles), second by the L1 request "
+                        "rate; HBM is nearly idle (the scene lives in L2 / Infinity Cache). achieved_algorithmic = SURVEY.md 8(d) bytes / kernel time counts "
+                        "every re-read the caches serve and is therefore not a fraction of the HBM peak; hbm.frac (PMC, this run) is."}
+        if n_gpus == 1:
+            cal = {}
+            try:
+                g0 = d.microbench_gather(0, False, 64, 0, 2 << 20, 2000, device=local_rank)
+                g1 = d.microbench_gather(0, False, 64, 0, 19 << 20, 2000, device=local_rank)
+                cal = {"l1_requests16_per_s_G_ceiling": g0["Grecords_per_s"] * 4, "random_19MB_table_records_per_s_G": g1["Grecords_per_s"]}
+            except d.DsrtError as e:
+                cal = {"error": str(e)[:160]}
+            pmc = None
+            if not args.no_pmc:
+                wl = ["--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", str(depth), "--frame", str(args.frame), "--tris", str(args.tris),
+                      "--bvh", args.bvh, "--stack-entries", str(args.stack_entries)] + (["--obj", args.obj] if args.obj else [])
+                pmc = pmc_counters(wl)
+            if pmc:
+                clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / secs if secs > 0 else 0.0          # Hz (sum over the 8 XCDs)
+                props = torch.cuda.get_device_properties(dev)
+                simds = props.multi_processor_count * 4
+                if pmc.get("SQ_INSTS_VALU") and clk:
+                    roof["achieved"] = pmc["SQ_INSTS_VALU"] / secs / 1e9
+                    roof["peak"] = simds * clk / VALU_CYCLES_PER_WAVE_INSTR / 1e9
+                    roof["frac"] = roof["achieved"] / roof["peak"]
+                    roof["valu_lane_occupancy"] = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc.get("SQ_ACTIVE_INST_VALU", 1.0))
+                    roof["shader_clock_GHz"] = clk / 1e9
+                if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum") and cal.get("l1_requests16_per_s_G_ceiling"):
+                    ach = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / secs / 1e9
+                    roof["l1"] = {"achieved": ach, "peak": cal["l1_requests16_per_s_G_ceiling"], "unit": "G 16-byte L1 requests/s", "frac": ach / cal["l1_requests16_per_s_G_ceiling"],
+                                  "l1_hit_rate": 1.0 - pmc.get("TCP_TCC_READ_REQ_sum", 0.0) / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                                  "l2_hit_rate": pmc.get("TCC_HIT_sum", 0.0) / max(1.0, pmc.get("TCC_HIT_sum", 0.0) + pmc.get("TCC_MISS_sum", 0.0))}
+                if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                    hbm_bytes = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0     # KiB counters; gfx950 FETCH_SIZE reads 1/2 (guide, section HBM)
+                    roof["traffic"] = hbm_bytes
+                    roof["hbm"] = {"achieved": hbm_bytes / secs / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_bytes / secs / 1e9 / HBM_PEAK_GBPS,
+                                   "fetch_size_raw_KiB": pmc["FETCH_SIZE"], "write_size_KiB": pmc["WRITE_SIZE"]}
+                roof["pmc"] = {k: pmc[k] for k in sorted(pmc)}
+            roof["calibration"] = cal
+
     if rank == 0:
         total_samples = W * H * spp
         out = {
@@ -417,23 +619,16 @@ def main():
                             f"{W}x{H} @ {spp} spp, max_depth {depth}, seed 1337, rng_mode 0 (reference LCG stream)",
                 "mesh_triangles": n_tris, "frame": args.frame, "width": W, "height": H, "spp": spp, "max_depth": depth,
                 "coverage": primary_hits / max(1.0, samples_counted), "rays_per_sample": rays / max(1.0, samples_counted),
+                "tiles_total_rank0": int(tiles_total), "tiles_culled_rank0": int(tiles_culled),
                 "parallelism": f"screen tiles 8x8 interleaved over {n_gpus} GPU(s)" + (", one RCCL gather + de-interleave per step" if shard else ""),
                 "bvh": args.bvh, "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
                 "strong_scaling_note": "rng_mode 0 keeps the reference's ONE LCG stream per pixel, so a pixel is a serial chain of spp samples; the slowest "
                                        "pixel of this frame needs about 0.4 s however many GPUs share the frame, which caps the speed-up near 2.5x "
                                        "(DESIGN.md section 5 has the per-rank times for 1/2/4/8 ranks and the rng_mode 1 column that does scale)",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": my_bytes / (my_kernel_ms * 1e-3) / 1e9 if my_kernel_ms > 0 else None,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": (my_bytes / (my_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if my_kernel_ms > 0 else None,
-                "traffic": traffic_from_profile(n_tris, args.frame, W, H, spp, depth, None if args.obj else meshgen.VERSION) if n_gpus == 1 else None,
-                "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms, "algorithmic_bytes_per_launch": my_bytes,
-                "note": "rank 0's launch; algorithmic bytes per SURVEY.md section 8(d) from the kernel's own work counters; latency/divergence-bound path; "
-                        "the formula charges every re-read of a node or triangle and those are served by L1/L2 (SURVEY.md H6), so frac can exceed 1; 'traffic' (bytes that left L2, PMC) is the HBM-side figure",
-            },
+            "setup": setup,
+            "lane_slots": lane_slots,
+            "roofline": roof,
         }
         if extras:
             out["extras"] = extras
@@ -442,7 +637,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget)
             if not args.no_extras:
-                out["cpu_baseline_book"] = book_baseline(obj, fr, host_cores())
+                out["cpu_baseline_book"] = book_baseline(obj, fr, host_cores(), os.path.join(ROOT, "gpurun_out", "timings_threads.tsv"))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

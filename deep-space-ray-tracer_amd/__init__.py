@@ -174,6 +174,15 @@ def shard_layout(desc):
     return {"tiles_total": total.value, "tiles_this_shard": mine.value, "tiles_per_shard_padded": padded.value, "rgb8_bytes_padded": nbytes.value}
 
 
+def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_bytes=19 << 20, iters=2000, device=0):
+    """Gather-rate calibration kernel (include/dsrt.h): returns {"ms", "records", "Grecords_per_s"}."""
+    ms, rec = C.c_float(), C.c_double()
+    _check(lib.dsrt_microbench_gather(int(device), int(mode), int(bool(dependent)), int(live_lanes), int(pad_valu), int(table_bytes), int(iters),
+                                      C.byref(ms), C.byref(rec)), "dsrt_microbench_gather")
+    return {"mode": mode, "dependent": bool(dependent), "live_lanes": live_lanes, "pad_valu": pad_valu, "table_MB": table_bytes / 2**20, "iters": iters,
+            "ms": ms.value, "records": rec.value, "Grecords_per_s": rec.value / ms.value / 1e6}
+
+
 def stats_dict(st):
     return {name: getattr(st, name) for name, _ in DsrtStats._fields_}
 
@@ -194,6 +203,14 @@ class Context:
 
     def __del__(self):
         self.close()
+
+    def clone(self):
+        """A second context on the same device sharing this one's resident scene (dsrt_ctx_clone)."""
+        h = C.c_void_p()
+        _check(lib.dsrt_ctx_clone(self._h, C.byref(h)), "dsrt_ctx_clone")
+        other = Context.__new__(Context)
+        other._h, other.device = h, self.device
+        return other
 
     def upload(self, scene_host_view):
         _check(lib.dsrt_scene_upload(self._h, C.byref(scene_host_view)), "dsrt_scene_upload")
@@ -236,3 +253,47 @@ class Context:
         out = np.zeros_like(x)
         _check(lib.dsrt_selftest_math(self._h, int(fn), x.ctypes.data, float(y), out.ctypes.data, int(x.size)), "dsrt_selftest_math")
         return out
+
+
+class Multi:
+    """All GPUs of a node from one process (DsrtMulti): tile-sharded frames with one RCCL gather, or whole frames dealt round-robin."""
+
+    def __init__(self, devices, frames_in_flight=1):
+        devs = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = C.c_void_p()
+        _check(lib.dsrt_multi_create(devs, len(devices), int(frames_in_flight), C.byref(h)), "dsrt_multi_create")
+        self._h, self.n = h, len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.dsrt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def uses_rccl(self):
+        return bool(lib.dsrt_multi_uses_rccl(self._h))
+
+    def upload(self, scene_host_view):
+        _check(lib.dsrt_multi_scene_upload(self._h, C.byref(scene_host_view)), "dsrt_multi_scene_upload")
+
+    def render_frame(self, desc, camera, sun_dir):
+        """-> (rgb8 image H x W x 3, per-rank kernel ms, wall seconds)"""
+        img = np.zeros((desc.height, desc.width, 3), np.uint8)
+        ms = (C.c_float * self.n)()
+        sec = C.c_double()
+        _check(lib.dsrt_multi_render_frame(self._h, C.byref(desc), C.byref(camera), _f3(sun_dir), img.ctypes.data, ms, C.byref(sec)), "dsrt_multi_render_frame")
+        return img, list(ms), sec.value
+
+    def render_sequence(self, desc, cameras, sun_dirs, want_images=True):
+        """Frame i whole on rank i mod N.  -> (list of images or None, wall seconds)"""
+        n = len(cameras)
+        cams = (GPUCamera * n)(*cameras)
+        suns = (C.c_float * (3 * n))(*[float(v) for s3 in sun_dirs for v in s3])
+        imgs = [np.zeros((desc.height, desc.width, 3), np.uint8) for _ in range(n)] if want_images else None
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs]) if want_images else None
+        sec = C.c_double()
+        _check(lib.dsrt_multi_render_sequence(self._h, C.byref(desc), cams, suns, n, ptrs, C.byref(sec)), "dsrt_multi_render_sequence")
+        return imgs, sec.value

@@ -105,9 +105,10 @@ EXPORTS = [
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_write_ppm", "dsrt_write_png",
-    "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_scene_upload", "dsrt_scene_upload_device",
+    "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
+    "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
     "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_render", "dsrt_deinterleave_tiles", "dsrt_render_to_host",
-    "dsrt_selftest_math", "dsrt_selftest_philox", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
+    "dsrt_selftest_math", "dsrt_selftest_philox", "dsrt_microbench_gather", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
 ]
 
 
@@ -145,6 +146,15 @@ def load():
     sig("dsrt_device_count", C.c_int, [])
     sig("dsrt_ctx_create", C.c_int, [C.c_int, P(vp)])
     sig("dsrt_ctx_destroy", None, [vp])
+    sig("dsrt_ctx_clone", C.c_int, [vp, P(vp)])
+    sig("dsrt_ctx_device", C.c_int, [vp])
+    sig("dsrt_multi_create", C.c_int, [P(C.c_int), C.c_int, C.c_int, P(vp)])
+    sig("dsrt_multi_destroy", None, [vp])
+    sig("dsrt_multi_count", C.c_int, [vp])
+    sig("dsrt_multi_uses_rccl", C.c_int, [vp])
+    sig("dsrt_multi_scene_upload", C.c_int, [vp, P(GPUScene)])
+    sig("dsrt_multi_render_frame", C.c_int, [vp, P(DsrtRenderDesc), P(GPUCamera), P(C.c_float), vp, P(C.c_float), P(C.c_double)])
+    sig("dsrt_multi_render_sequence", C.c_int, [vp, P(DsrtRenderDesc), P(GPUCamera), P(C.c_float), C.c_int, P(vp), P(C.c_double)])
     sig("dsrt_scene_upload", C.c_int, [vp, P(GPUScene)])
     sig("dsrt_scene_upload_device", C.c_int, [vp, P(GPUScene)])
     sig("dsrt_scene_set_camera_sun", C.c_int, [vp, P(GPUCamera), P(C.c_float)])
@@ -154,6 +164,7 @@ def load():
     sig("dsrt_render_to_host", C.c_int, [vp, P(DsrtRenderDesc), vp, vp, P(DsrtStats)])
     sig("dsrt_selftest_math", C.c_int, [vp, C.c_int, vp, C.c_float, vp, C.c_int])
     sig("dsrt_selftest_philox", C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp])
+    sig("dsrt_microbench_gather", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, P(C.c_float), P(C.c_double)])
     sig("gpu_render_scene", None, [P(GPUScene), C.c_int, C.c_int])
     sig("dsrt_build_gpu_scene", C.c_int, [vp, P(GPUCamera), P(C.c_float), P(GPUScene)])
     sig("dsrt_free_gpu_scene", None, [P(GPUScene)])

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,7 +24,7 @@
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
-hipError_t launch_resolve(const float* partial, int chunks, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
+hipError_t launch_resolve(const RenderArgs& a, int local_tiles, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
                                size_t shard_stride_bytes, hipStream_t stream);
@@ -32,11 +33,17 @@ int kernel_waves_per_block();
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
                              uint32_t resident_lanes, bool cull, hipStream_t stream);
 hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream);
+hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
 }  // namespace dsrt
 
 using namespace dsrt;
 
 namespace {
+
+// Frames in flight on separate streams (dsrt_ctx_clone, dsrt_multi_render_sequence) only overlap on the device if each stream
+// gets a hardware queue of its own; the HIP runtime maps streams onto 4 unless told otherwise BEFORE it initialises.  The
+// library asks for 16 when it is loaded, unless the host has set the variable itself.  (No effect if HIP is already up.)
+struct HwQueuesDefault { HwQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queues_default;
 
 bool hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -239,16 +246,35 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
 struct DsrtContext {
     int device = 0;
     int num_cus = 0;
-    PackedScene scene;
+    // The resident scene is shared between a context and its clones (dsrt_ctx_clone): one copy in HBM however many frames are in
+    // flight.  Camera and sun are per context (they are what changes per frame); so are the working buffers below.
+    std::shared_ptr<PackedScene> scene;
+    GPUCamera camera{};
+    DsrtF3 sun_dir{}, sun_radiance{};
+    int sun_enabled = 0;
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp;
     DevBuf<float> partial;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); }
+    hipEvent_t done = nullptr;      // recorded behind every render: the next render on ANY stream waits for it (queue words, spill strip,
+    bool done_valid = false;        // pre-pass arrays and partial sums are per context, so a context has one render in flight)
+    ~DsrtContext() { if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); if (done) (void)hipEventDestroy(done); }
 };
 
 namespace {
+
+// A fresh PackedScene for this context (clones made earlier keep the one they share until they are re-cloned or destroyed).
+int install_scene(DsrtContext* ctx, const GPUScene& host_layout) {
+    auto fresh = std::make_shared<PackedScene>();
+    ctx->scene.reset();
+    const int rc = pack_scene(host_layout, *fresh);
+    if (rc) return rc;
+    ctx->scene = std::move(fresh);
+    ctx->camera = ctx->scene->camera;
+    ctx->sun_dir = ctx->scene->sun_dir; ctx->sun_radiance = ctx->scene->sun_radiance; ctx->sun_enabled = ctx->scene->sun_enabled;
+    return DSRT_OK;
+}
 
 constexpr size_t kQueueLightWord = 64;                       // the light queue's counter: its own cache line, past the counters
 constexpr size_t kCtrlWords = kQueueLightWord + 16;
@@ -296,10 +322,23 @@ int dsrt_ctx_create(int device, DsrtContext** out) {
     ctx->num_cus = prop.multiProcessorCount;
     int rc = ctx->ctrl.alloc(kCtrlWords);
     if (rc) { delete ctx; return rc; }
-    if (!hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate")) { delete ctx; return DSRT_ERR_HIP; }
+    if (!hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate") ||
+        !hip_ok(hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming), "hipEventCreateWithFlags")) { delete ctx; return DSRT_ERR_HIP; }
     *out = ctx;
     return DSRT_OK;
 }
+
+int dsrt_ctx_clone(const DsrtContext* src, DsrtContext** out) {
+    if (!src || !out) { set_error("dsrt_ctx_clone: null argument"); return DSRT_ERR_INVALID; }
+    const int rc = dsrt_ctx_create(src->device, out);
+    if (rc) return rc;
+    (*out)->scene = src->scene;                    // shared, read-only on the device
+    (*out)->camera = src->camera;
+    (*out)->sun_dir = src->sun_dir; (*out)->sun_radiance = src->sun_radiance; (*out)->sun_enabled = src->sun_enabled;
+    return DSRT_OK;
+}
+
+int dsrt_ctx_device(const DsrtContext* ctx) { return ctx ? ctx->device : -1; }
 
 void dsrt_ctx_destroy(DsrtContext* ctx) {
     if (!ctx) return;
@@ -308,13 +347,15 @@ void dsrt_ctx_destroy(DsrtContext* ctx) {
 }
 
 int dsrt_scene_upload(DsrtContext* ctx, const GPUScene* scene) {
+    return dsrt::guarded("dsrt_scene_upload", [&]() -> int {
     if (!ctx || !scene) { set_error("dsrt_scene_upload: null argument"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
-    ctx->scene.valid = false;
-    return pack_scene(*scene, ctx->scene);
+    return install_scene(ctx, *scene);
+    });
 }
 
 int dsrt_scene_upload_device(DsrtContext* ctx, const GPUScene* d) {
+    return dsrt::guarded("dsrt_scene_upload_device", [&]() -> int {
     if (!ctx || !d) { set_error("dsrt_scene_upload_device: null argument"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
     if (d->num_triangles < 0 || d->num_spheres < 0 || d->num_materials < 0 || d->num_bvh_nodes < 0 || d->num_textures < 0 || d->texture_pool_floats < 0) {
@@ -345,15 +386,15 @@ int dsrt_scene_upload_device(DsrtContext* ctx, const GPUScene* d) {
     h.bvh_nodes = nodes.empty() ? nullptr : nodes.data();
     h.textures = th.empty() ? nullptr : th.data();
     h.texture_pool = pool.empty() ? nullptr : pool.data();
-    ctx->scene.valid = false;
-    return pack_scene(h, ctx->scene);
+    return install_scene(ctx, h);
+    });
 }
 
 int dsrt_scene_set_camera_sun(DsrtContext* ctx, const GPUCamera* cam, const float sun_dir_model[3]) {
     if (!ctx || !cam) { set_error("dsrt_scene_set_camera_sun: null argument"); return DSRT_ERR_INVALID; }
-    if (!ctx->scene.valid) { set_error("no scene uploaded"); return DSRT_ERR_NO_SCENE; }
-    ctx->scene.camera = *cam;
-    if (sun_dir_model) ctx->scene.sun_dir = DsrtF3{sun_dir_model[0], sun_dir_model[1], sun_dir_model[2]};
+    if (!ctx->scene || !ctx->scene->valid) { set_error("no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    ctx->camera = *cam;
+    if (sun_dir_model) ctx->sun_dir = DsrtF3{sun_dir_model[0], sun_dir_model[1], sun_dir_model[2]};
     return DSRT_OK;
 }
 
@@ -369,26 +410,27 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
 
 int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream_v, DsrtStats* stats) {
     if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
-    if (!ctx->scene.valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    if (!ctx->scene || !ctx->scene->valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
     if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
     Tiling t;
     if (!make_tiling(*desc, t)) { set_error("dsrt_render: bad size, tile or shard"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_v;
-    const PackedScene& sc = ctx->scene;
+    const PackedScene& sc = *ctx->scene;
+    if (ctx->done_valid) HIP_TRY(hipStreamWaitEvent(stream, ctx->done, 0));     // a context's working buffers serve one render at a time
 
     RenderArgs a;
     std::memset(&a, 0, sizeof a);
     a.scene = sc.view;
     FrameParams& f = a.frame;
-    const GPUCamera& c = sc.camera;
+    const GPUCamera& c = ctx->camera;
     f.cam_origin[0] = c.origin.x; f.cam_origin[1] = c.origin.y; f.cam_origin[2] = c.origin.z;
     f.cam_llc[0] = c.lower_left_corner.x; f.cam_llc[1] = c.lower_left_corner.y; f.cam_llc[2] = c.lower_left_corner.z;
     f.cam_horizontal[0] = c.horizontal.x; f.cam_horizontal[1] = c.horizontal.y; f.cam_horizontal[2] = c.horizontal.z;
     f.cam_vertical[0] = c.vertical.x; f.cam_vertical[1] = c.vertical.y; f.cam_vertical[2] = c.vertical.z;
-    f.sun_dir[0] = sc.sun_dir.x; f.sun_dir[1] = sc.sun_dir.y; f.sun_dir[2] = sc.sun_dir.z;
-    f.sun_radiance[0] = sc.sun_radiance.x; f.sun_radiance[1] = sc.sun_radiance.y; f.sun_radiance[2] = sc.sun_radiance.z;
-    f.sun_enabled = sc.sun_enabled;
+    f.sun_dir[0] = ctx->sun_dir.x; f.sun_dir[1] = ctx->sun_dir.y; f.sun_dir[2] = ctx->sun_dir.z;
+    f.sun_radiance[0] = ctx->sun_radiance.x; f.sun_radiance[1] = ctx->sun_radiance.y; f.sun_radiance[2] = ctx->sun_radiance.z;
+    f.sun_enabled = ctx->sun_enabled;
     f.width = desc->width; f.height = desc->height;
     f.spp = desc->spp < 1 ? 1 : desc->spp;                              // src/gpu_render.cu:987-988
     f.max_depth = desc->max_depth > 0 ? desc->max_depth : 12;           // :723-725
@@ -415,7 +457,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         f.total_items *= (uint32_t)f.chunks;
         const size_t words = out_pixels * (size_t)f.chunks * 3;
         if (ctx->partial.n < words) { int rc = ctx->partial.alloc(words); if (rc) return rc; }
-        HIP_TRY(hipMemsetAsync(ctx->partial.p, 0, words * sizeof(float), stream));
+        // not cleared: only pixels of the heavy tiles are sliced, every slice of such a pixel is written by exactly one work item,
+        // and dsrt_resolve_kernel reads nothing else (the other pixels are tone-mapped and stored by the lane that rendered them)
         a.partial = ctx->partial.p;
     }
     a.out_rgb8 = d_rgb8;
@@ -454,10 +497,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     // see dsrt_tile_cost_kernel).  tune[3] == 1 switches both off, == 2 keeps the order but culls nothing; counting builds never
     // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
     // tiles that see geometry and the number of tiles in the order.
-    if (ctx->tile_cost.n < (size_t)t.mine + 64) {
-        int rc;
-        if ((rc = ctx->tile_cost.alloc((size_t)t.mine + 64)) || (rc = ctx->tile_order.alloc((size_t)t.mine + 64)) ||
-            (rc = ctx->tile_work.alloc((size_t)t.mine + 64)) || (rc = ctx->tile_tmp.alloc((size_t)t.mine + 64))) return rc;
+    for (DevBuf<uint32_t>* b : {&ctx->tile_cost, &ctx->tile_order, &ctx->tile_work, &ctx->tile_tmp}) {      // each by its own size: a failed
+        if (b->n < (size_t)t.mine + 64) { int rc = b->alloc((size_t)t.mine + 64); if (rc) return rc; }      // allocation leaves no stale sibling
     }
     uint32_t* sched = ctx->tile_cost.p + t.mine + 32;       // {tiles that see geometry, tiles in the order, heavy lanes per wave}
     a.sched = sched;
@@ -492,7 +533,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
     HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
-    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.partial, f.chunks, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
+    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a, t.mine, stream));
+    HIP_TRY(hipEventRecord(ctx->done, stream));
+    ctx->done_valid = true;
     if (stats) {
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -537,6 +580,7 @@ int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const 
 }
 
 int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h_rgb8, float* h_f32, DsrtStats* stats) {
+    return dsrt::guarded("dsrt_render_to_host", [&]() -> int {
     if (!ctx || !desc || !h_rgb8) { set_error("dsrt_render_to_host: null argument"); return DSRT_ERR_INVALID; }
     if (desc->shard_count > 1) { set_error("dsrt_render_to_host renders whole images only"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -552,6 +596,7 @@ int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h
     HIP_TRY(hipMemcpy(h_rgb8, d8.p, px * 3, hipMemcpyDeviceToHost));
     if (h_f32) HIP_TRY(hipMemcpy(h_f32, d32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return DSRT_OK;
+    });
 }
 
 int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n) {
@@ -583,9 +628,44 @@ int dsrt_selftest_philox(DsrtContext* ctx, uint64_t seed, uint64_t subsequence, 
 // =========================================================================================
 // Drop-in layer
 // =========================================================================================
+static void gpu_render_scene_body(const GPUScene* scene, int width, int height);
 namespace {
 std::mutex g_dropin_mutex;
 DsrtContext* g_dropin_ctx = nullptr;
+
+// The reference calls build_gpu_scene + gpu_render_scene + free_gpu_scene once per FRAME (src/main.cpp:405-428) although only camera
+// and sun change between frames.  gpu_render_scene receives device arrays in the reference layouts; converting them (copy to the
+// host, re-layout, upload) costs far more than rendering a far frame.  So the drop-in keeps the converted scene of the previous call
+// and re-uses it when the arrays it is handed have the same CONTENT: a 128-bit position-dependent hash of every array, computed on
+// the device (one pass over ~150 MB at 1 M triangles: well under a millisecond), plus all the counts.  Pointer equality would not do --
+// the reference frees and re-allocates the arrays every frame, so equal pointers can hold different data and vice versa.
+struct SceneFingerprint {
+    uint64_t h[2] = {0, 0};
+    int counts[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool valid = false;
+    bool operator==(const SceneFingerprint& o) const { return valid && o.valid && h[0] == o.h[0] && h[1] == o.h[1] && !std::memcmp(counts, o.counts, sizeof counts); }
+};
+SceneFingerprint g_dropin_fp;
+DevBuf<uint64_t> g_dropin_hash;
+
+int fingerprint_device_scene(const GPUScene& d, SceneFingerprint& fp) {
+    fp = SceneFingerprint{};
+    const int counts[7] = {d.num_triangles, d.num_spheres, d.num_materials, d.num_bvh_nodes, d.num_textures, d.texture_pool_floats, d.tri_indices ? 1 : 0};
+    std::memcpy(fp.counts, counts, sizeof counts);
+    for (int c : counts) if (c < 0) { set_error("scene has a negative count"); return DSRT_ERR_INVALID; }
+    if (g_dropin_hash.n < 2) { int rc = g_dropin_hash.alloc(2); if (rc) return rc; }
+    HIP_TRY(hipMemsetAsync(g_dropin_hash.p, 0, 2 * sizeof(uint64_t), nullptr));
+    struct Arr { const void* p; size_t bytes; } arrs[7] = {
+        {d.triangles, (size_t)d.num_triangles * sizeof(GPUTriangle)}, {d.spheres, (size_t)d.num_spheres * sizeof(GPUSphere)},
+        {d.materials, (size_t)d.num_materials * sizeof(GPUMaterial)}, {d.bvh_nodes, (size_t)d.num_bvh_nodes * sizeof(GPUBVHNode)},
+        {d.textures, (size_t)d.num_textures * sizeof(GPUTextureHeader)}, {d.texture_pool, (size_t)d.texture_pool_floats * sizeof(float)},
+        {d.tri_indices, d.tri_indices ? (size_t)d.num_triangles * sizeof(int) : 0}};
+    for (int a = 0; a < 7; ++a)
+        if (arrs[a].p && arrs[a].bytes) HIP_TRY(launch_content_hash((const uint32_t*)arrs[a].p, arrs[a].bytes / 4, 0x9E3779B97F4A7C15ull * (uint64_t)(a + 1), g_dropin_hash.p, nullptr));
+    HIP_TRY(hipMemcpy(fp.h, g_dropin_hash.p, sizeof fp.h, hipMemcpyDeviceToHost));
+    fp.valid = true;
+    return DSRT_OK;
+}
 
 DsrtContext* dropin_context() {
     if (!g_dropin_ctx) {
@@ -598,6 +678,7 @@ DsrtContext* dropin_context() {
 }  // namespace
 
 int dsrt_build_gpu_scene(const DsrtHostScene* hs, const GPUCamera* cam, const float sun_dir_model[3], GPUScene* out) {
+    return dsrt::guarded("dsrt_build_gpu_scene", [&]() -> int {
     if (!hs || !cam || !out) { set_error("dsrt_build_gpu_scene: null argument"); return DSRT_ERR_INVALID; }
     GPUScene h;
     int rc = dsrt_host_scene_view(hs, &h);
@@ -622,6 +703,7 @@ int dsrt_build_gpu_scene(const DsrtHostScene* hs, const GPUCamera* cam, const fl
     if ((rc = push(h.texture_pool, (size_t)h.texture_pool_floats * sizeof(float), &p))) return rc; d.texture_pool = (const float*)p;
     *out = d;
     return DSRT_OK;
+    });
 }
 
 void dsrt_free_gpu_scene(GPUScene* s) {                                  // src/gpu_scene_builder.cpp:603-626
@@ -643,11 +725,25 @@ void dsrt_free_gpu_scene(GPUScene* s) {                                  // src/
 }
 
 void gpu_render_scene(const GPUScene* scene, int width, int height) {
+    (void)dsrt::guarded("gpu_render_scene", [&]() -> int { gpu_render_scene_body(scene, width, height); return DSRT_OK; });
+}
+
+static void gpu_render_scene_body(const GPUScene* scene, int width, int height) {
     std::lock_guard<std::mutex> lock(g_dropin_mutex);
     if (!scene) { std::fprintf(stderr, "gpu_render_scene: null scene\n"); return; }
     DsrtContext* ctx = dropin_context();
     if (!ctx) { std::fprintf(stderr, "gpu_render_scene: %s\n", dsrt_last_error()); return; }
-    if (dsrt_scene_upload_device(ctx, scene) != DSRT_OK) { std::fprintf(stderr, "gpu_render_scene: scene upload failed: %s\n", dsrt_last_error()); return; }
+    SceneFingerprint fp;
+    if (fingerprint_device_scene(*scene, fp) != DSRT_OK) { std::fprintf(stderr, "gpu_render_scene: %s\n", dsrt_last_error()); return; }
+    if (ctx->scene && ctx->scene->valid && fp == g_dropin_fp) {
+        // same geometry, materials and textures as the previous call: only the per-frame part of the header is taken over
+        ctx->camera = scene->camera;
+        ctx->sun_dir = scene->sun_dir; ctx->sun_radiance = scene->sun_radiance; ctx->sun_enabled = scene->sun_enabled ? 1 : 0;
+    } else {
+        g_dropin_fp.valid = false;
+        if (dsrt_scene_upload_device(ctx, scene) != DSRT_OK) { std::fprintf(stderr, "gpu_render_scene: scene upload failed: %s\n", dsrt_last_error()); return; }
+        g_dropin_fp = fp;
+    }
     DsrtRenderDesc d;
     std::memset(&d, 0, sizeof d);
     d.width = width; d.height = height;

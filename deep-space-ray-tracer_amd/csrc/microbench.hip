@@ -1,0 +1,179 @@
+// microbench.hip -- calibration kernels for the roofline of the render kernel (include/dsrt.h: dsrt_microbench_gather).
+//
+// The render kernel's dominant memory operation is a fully divergent GATHER: every live lane of a wave reads its own 64-byte
+// node record (four 16-byte loads) from a table of a few tens of MB that lives in L2 / Infinity Cache.  What bounds that is
+// not HBM (the counters show 0.08 of the HBM peak) but how many 16-byte requests per cycle a CU's vector L1 (TA/TCP) accepts.
+// These kernels have the render kernel's launch shape -- 256-thread workgroups, 4 waves per SIMD, grid = resident set, every
+// lane gathering random aligned 64-byte records from a table of the node array's size -- and nothing else, so that their
+// record rate is the ceiling of that access shape on the device the bench runs on:
+//   mode 0  lane gather        each lane reads its record with 4 x global_load_dwordx4 (what the render kernel does)
+//   mode 1  quad gather, DMA   the 4 lanes of a quad read ONE record per load instruction (16 B each, 64 contiguous bytes) with
+//                              global_load_lds_dwordx4 into a per-wave LDS tile; each lane reads its record back with 4 x ds_read_b128
+//   mode 2  quad gather, regs  same, through registers: global_load_dwordx4 + ds_write_b128 + ds_read_b128
+// `dependent` chains the next record index on the loaded data (a traversal step cannot start before the previous record is in);
+// `live` of the 64 lanes of every wave take part (the others are masked off, as in a half-empty traversal loop);
+// `pad` v_fma per loaded record (rounded up to 16) stand in for the slab arithmetic between two node fetches.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dsrt.h"
+#include "../host/host_internal.hpp"
+
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+constexpr int kTileStride = 64 + 1;           // in float4: one 1-KiB DMA piece per tile; 16 bytes of padding rotate the banks between the four tiles
+
+template <int MODE, bool DEP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+gather_kernel(const float4* __restrict__ table, uint32_t n_rec, int iters, int live, int pad, float* __restrict__ sink) {
+    __shared__ float4 tiles[4][4 * kTileStride];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = (mix32((glane >> 6) * 64u + ((lane * 37u + 11u) & 63u)) & 63u) < (uint32_t)live || live >= 64;
+    uint32_t state = mix32(glane * 2654435761u + 12345u);
+    float acc = 0.0f;
+    float4* const my_tiles = tiles[wave];
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t idx = __umulhi(state, n_rec);                      // 0 .. n_rec-1
+        float4 q0, q1, q2, q3;
+        if (MODE == 0) {
+            if (active) {
+                const float4* rec = table + (size_t)idx * 4;
+                q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+            } else { q0 = q1 = q2 = q3 = make_float4(0, 0, 0, 0); }
+        } else {
+            // quad-cooperative: load instruction j fetches the records of lanes 4q + j; lane l supplies bytes [16 (l & 3), +16)
+            float4 part[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // quad broadcast of lane 4q + j's index and live bit (DPP quad_perm [j,j,j,j]: a plain VALU move, no LDS)
+                const int mine_packed = (int)(idx | (active ? 0x80000000u : 0u));
+                const uint32_t packed = (uint32_t)(j == 0 ? __builtin_amdgcn_mov_dpp(mine_packed, 0x00, 0xF, 0xF, true)
+                                                 : j == 1 ? __builtin_amdgcn_mov_dpp(mine_packed, 0x55, 0xF, 0xF, true)
+                                                 : j == 2 ? __builtin_amdgcn_mov_dpp(mine_packed, 0xAA, 0xF, 0xF, true)
+                                                          : __builtin_amdgcn_mov_dpp(mine_packed, 0xFF, 0xF, 0xF, true));
+                const uint32_t oidx = packed & 0x7FFFFFFFu;
+                const bool oact = (packed >> 31) != 0u;
+                const float4* src = table + (size_t)oidx * 4 + (lane & 3u);
+                if (MODE == 1) {
+                    if (oact) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(my_tiles + j * kTileStride), 16, 0, 0);
+                } else {
+                    part[j] = oact ? *src : make_float4(0, 0, 0, 0);
+                }
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) my_tiles[j * kTileStride + lane] = part[j];
+            }
+            if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (active) {
+                // four ds_read_b128 and their wait in one statement (hipcc would re-split the reads around the arithmetic below)
+                const uint32_t mine = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(my_tiles + (lane & 3u) * kTileStride + (lane >> 2) * 4u);
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v r0, r1, r2, r3;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(mine) : "memory");
+                q0 = make_float4(r0.x, r0.y, r0.z, r0.w); q1 = make_float4(r1.x, r1.y, r1.z, r1.w);
+                q2 = make_float4(r2.x, r2.y, r2.z, r2.w); q3 = make_float4(r3.x, r3.y, r3.z, r3.w);
+            } else { q0 = q1 = q2 = q3 = make_float4(0, 0, 0, 0); }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float v = (((q0.x + q1.y) + (q2.z + q3.w)) + ((q0.w + q1.z) + (q2.y + q3.x))) + (((q0.y + q1.x) + (q2.w + q3.z)) + ((q0.z + q1.w) + (q2.x + q3.y)));
+        {   // `pad` v_fma per record in four interleaved chains, 16 per trip of the loop (its scalar overhead is amortised 16 times)
+            float a0 = v, a1 = q0.y, a2 = q1.x, a3 = q2.z;
+            for (int p = 0; p < pad; p += 16) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0 = __builtin_fmaf(a0, 1.0000001f, a1); a1 = __builtin_fmaf(a1, 0.9999999f, a2);
+                    a2 = __builtin_fmaf(a2, 1.0000001f, a3); a3 = __builtin_fmaf(a3, 0.9999999f, a0);
+                }
+            }
+            v = (a0 + a1) + (a2 + a3);
+        }
+        acc += v;
+        state = DEP ? mix32(state ^ __float_as_uint(v)) : mix32(state + 0x9E3779B9u);
+    }
+    if (acc == 123.456f) sink[glane] = acc;           // keeps the loads alive; never true for the table's contents
+}
+
+template <int MODE>
+hipError_t launch_gather(bool dep, const float4* table, uint32_t n_rec, int iters, int live, int pad, float* sink, int blocks, hipStream_t s) {
+    if (dep) hipLaunchKernelGGL((gather_kernel<MODE, true>), dim3(blocks), dim3(256), 0, s, table, n_rec, iters, live, pad, sink);
+    else     hipLaunchKernelGGL((gather_kernel<MODE, false>), dim3(blocks), dim3(256), 0, s, table, n_rec, iters, live, pad, sink);
+    return hipGetLastError();
+}
+
+bool ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    dsrt::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define MB_TRY(expr) do { if (!ok((expr), #expr)) { cleanup(); return DSRT_ERR_HIP; } } while (0)
+
+}  // namespace
+
+extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, int pad_valu, size_t table_bytes, int iters,
+                                      float* out_ms, double* out_records) {
+    if (mode < 0 || mode > 2 || live_lanes < 1 || live_lanes > 64 || pad_valu < 0 || pad_valu > 4096 || iters < 1 || iters > (1 << 20) ||
+        table_bytes < 4096 || table_bytes > ((size_t)1 << 34) || !out_ms || !out_records) {
+        dsrt::set_error("dsrt_microbench_gather: bad argument");
+        return DSRT_ERR_INVALID;
+    }
+    float4* table = nullptr;
+    float* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (table) (void)hipFree(table);
+        if (sink) (void)hipFree(sink);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    MB_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MB_TRY(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount * 4;              // the render kernel's resident set
+    const uint32_t n_rec = (uint32_t)(table_bytes / 64);
+    MB_TRY(hipMalloc((void**)&table, (size_t)n_rec * 64));
+    MB_TRY(hipMalloc((void**)&sink, (size_t)blocks * 256 * sizeof(float)));
+    {
+        std::vector<float> host((size_t)n_rec * 16);
+        uint32_t s = 1u;
+        for (float& f : host) { s = s * 1664525u + 1013904223u; f = (float)(s >> 8) * (1.0f / 16777216.0f); }
+        MB_TRY(hipMemcpy(table, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    auto run = [&](int n) -> hipError_t {
+        if (mode == 0) return launch_gather<0>(dependent != 0, table, n_rec, n, live_lanes, pad_valu, sink, blocks, nullptr);
+        if (mode == 1) return launch_gather<1>(dependent != 0, table, n_rec, n, live_lanes, pad_valu, sink, blocks, nullptr);
+        return launch_gather<2>(dependent != 0, table, n_rec, n, live_lanes, pad_valu, sink, blocks, nullptr);
+    };
+    MB_TRY(run(iters < 64 ? iters : 64));                         // warm the caches and the clocks
+    MB_TRY(hipDeviceSynchronize());
+    MB_TRY(hipEventRecord(e0, nullptr));
+    MB_TRY(run(iters));
+    MB_TRY(hipEventRecord(e1, nullptr));
+    MB_TRY(hipEventSynchronize(e1));
+    MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
+    // live lanes are chosen per lane by a hash: count them the same way on the host
+    double live_total = 0;
+    for (uint32_t g = 0; g < (uint32_t)blocks * 256u; ++g) {
+        const uint32_t lane = g & 63u;
+        uint32_t x = (g >> 6) * 64u + ((lane * 37u + 11u) & 63u);
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        if (live_lanes >= 64 || (x & 63u) < (uint32_t)live_lanes) live_total += 1.0;
+    }
+    *out_records = live_total * (double)iters;
+    cleanup();
+    return DSRT_OK;
+}

@@ -30,12 +30,20 @@ enum : int {
 // touches L (the next hit's terms, the end of the sample), i.e. in the reference's order; at most one delegated ray per path
 // is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
 // the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
-//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding;
+//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding; bit 9 kSliced;
 //              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`;
 //              bits 24-31: probe launch only: rays traced for the current pixel (saturating)
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
+constexpr uint32_t kSliced = 1u << 9;       // rng_mode 1: the current work item is one slice of a pixel's samples (its sum goes to `partial`)
+
+// Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
+// the DS unit retires a wave's operations in order, so no hardware instruction is needed; what IS needed is that the compiler
+// keeps the writer's stores ahead of, and the reader's loads behind, the ballot that separates them.  A wavefront-scope fence
+// says exactly that and costs no ISA.
+__device__ __forceinline__ void lane_handoff_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+__device__ __forceinline__ void lane_handoff_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 constexpr uint32_t kStepCap = 1u << 22;     // no ray walks more node/leaf steps than this (guards against corrupt input)
 
@@ -121,6 +129,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     // Join: a runnable lane with a delegated shadow ray has its answer (the kernel parks it otherwise): add the sun term now, before
     // this step can touch L, exactly where the reference adds it (:816-834).
     if (ln.aux & kAwait) {
+        lane_handoff_acquire();
         if (ln.pend[12 * kPendStride] == 2.0f) L = L + pend_get(ln, 0);
         ln.aux &= ~kAwait;
     }
@@ -143,6 +152,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const uint32_t owner_plus1 = (ln.aux >> 16) & 0x7Fu;
         if (owner_plus1) {                                    // traced for another lane: hand the answer over, be free again
             strip_of(owner_plus1 - 1u)[12 * kPendStride] = blocked ? 1.0f : 2.0f;
+            lane_handoff_release();                            // the answer word is read by ANOTHER lane of this wave (poll in render_body)
             ln.aux &= 0xFF00FFFFu;
             state = ST_DONE;
         } else {
@@ -314,6 +324,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                             ln.pend[13 * kPendStride + ((int)rank - (int)my_lane)] = __uint_as_float(my_lane);
                             pend_put(ln, 3, sh_o); pend_put(ln, 6, sh_d);
                             ln.pend[12 * kPendStride] = 0.0f;
+                            lane_handoff_release();            // request table, ray and cleared answer word: read by the helper lane below
                             ln.aux |= kAwait;
                             delegated = true;
                             need_shadow = false;
@@ -340,6 +351,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         if (handed != 0ull && state == ST_DONE) {
             const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_mask, 0u));
             if (r < (uint32_t)__popcll(handed)) {
+                lane_handoff_acquire();
                 const uint32_t owner = __float_as_uint(ln.pend[13 * kPendStride + ((int)r - (int)my_lane)]);
                 const float* theirs = strip_of(owner);
                 ro = mk(theirs[3 * kPendStride], theirs[4 * kPendStride], theirs[5 * kPendStride]);
@@ -362,7 +374,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         else launch = 1;
     }
     if (state == ST_GEN && sample >= ln.sample_end) {       // sample_end == spp with rng_mode 0
-        if constexpr (RNGMODE == 1) {
+        if (RNGMODE == 1 && (ln.aux & kSliced)) {
             // this slice of the pixel's samples is done: its partial sum goes to the slice's own slot; dsrt_resolve_kernel
             // adds the slices in order and tone-maps
             float* dst = args.partial + ((size_t)out_index * (size_t)P.chunks + ln.chunk) * 3;
@@ -413,6 +425,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         }
         const bool sliced = RNGMODE == 1 && heavy;
         ln.chunk = 0;
+        ln.aux = sliced ? (ln.aux | kSliced) : (ln.aux & ~kSliced);
         const bool none = item >= (heavy ? heavy_items : light_items);
         if (sliced) { ln.chunk = item % per_pixel; item /= per_pixel; }
         if (!heavy) item += n_heavy * tt;                     // position in tile_order x pixels per tile

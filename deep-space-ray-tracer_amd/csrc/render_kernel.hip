@@ -67,6 +67,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             // lanes whose delegated shadow ray (path_machine.h) has not answered yet step aside; those whose answer came are back
             if (wave_any((ln.aux & kAwait) != 0u)) {
                 if (ln.aux & kAwait) {
+                    lane_handoff_acquire();
                     const bool answered = ln.pend[12 * kPendStride] != 0.0f;
                     if (state >= kParked) { if (answered) state -= kParked; }
                     else if (state < ST_TRAV_CLOSEST && !answered) state += kParked;
@@ -454,23 +455,34 @@ __global__ void dsrt_math_kernel(int fn, const float* __restrict__ x, float y, f
     out[i] = fn == 0 ? dsrt_sinf(x[i]) : (fn == 1 ? dsrt_cosf(x[i]) : dsrt_powf(x[i], y));
 }
 
-// rng_mode 1: add a pixel's sample slices in slice order, then the reference's tone map and 8-bit store (:1003-1030).
-__global__ void dsrt_resolve_kernel(const float* __restrict__ partial, int chunks, int spp, float inv_gamma, size_t n_pixels,
-                                    uint8_t* __restrict__ out_rgb8, float* __restrict__ out_f32) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
+// rng_mode 1: add a pixel's sample slices in slice order, then the reference's tone map and 8-bit store (:1003-1030).  Only the
+// pixels of the HEAVY tiles were sliced (the first sched[0] entries of tile_order; ST_FETCH in path_machine.h): the others were
+// finished by the lane that rendered them, and their partial-sum slots were never written.
+__global__ void dsrt_resolve_kernel(const RenderArgs args) {
+    const FrameParams& P = args.frame;
+    const uint32_t tt = (uint32_t)(P.tile * P.tile);
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= (size_t)args.sched[0] * tt) return;
+    const uint32_t within = (uint32_t)(item % tt);
+    const uint32_t k = P.tile_order ? P.tile_order[item / tt] : (uint32_t)(item / tt);
+    const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
+    const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
+    const uint32_t in_x = within % (uint32_t)P.tile, in_y = within / (uint32_t)P.tile;
+    const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
+    if (x >= P.width || row >= P.height) return;
+    const size_t i = P.compact_output ? ((size_t)k * tt + (size_t)in_y * (size_t)P.tile + in_x) : ((size_t)row * (size_t)P.width + (size_t)x);
     F3 acc = mk(0, 0, 0);
-    for (int k = 0; k < chunks; ++k) acc = acc + ld3(partial + (i * (size_t)chunks + (size_t)k) * 3);
-    const float inv_spp = 1.0f / (float)spp;
+    for (int c = 0; c < P.chunks; ++c) acc = acc + ld3(args.partial + (i * (size_t)P.chunks + (size_t)c) * 3);
+    const float inv_spp = 1.0f / (float)P.spp;
     F3 col = acc * inv_spp;
     col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
     col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
-    col = mk(dsrt_powf(col.x, inv_gamma), dsrt_powf(col.y, inv_gamma), dsrt_powf(col.z, inv_gamma));
+    col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
     col = clamp01(col);
-    out_rgb8[i * 3 + 0] = (unsigned char)(255.99f * col.x);
-    out_rgb8[i * 3 + 1] = (unsigned char)(255.99f * col.y);
-    out_rgb8[i * 3 + 2] = (unsigned char)(255.99f * col.z);
-    if (out_f32) { out_f32[i * 3 + 0] = col.x; out_f32[i * 3 + 1] = col.y; out_f32[i * 3 + 2] = col.z; }
+    args.out_rgb8[i * 3 + 0] = (unsigned char)(255.99f * col.x);
+    args.out_rgb8[i * 3 + 1] = (unsigned char)(255.99f * col.y);
+    args.out_rgb8[i * 3 + 2] = (unsigned char)(255.99f * col.z);
+    if (args.out_f32) { args.out_f32[i * 3 + 0] = col.x; args.out_f32[i * 3 + 1] = col.y; args.out_f32[i * 3 + 2] = col.z; }
 }
 
 // ---- launchers (called from device_api.hip) -----------------------------------------------------------
@@ -500,8 +512,10 @@ hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_resolve(const float* partial, int chunks, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream) {
-    hipLaunchKernelGGL(dsrt_resolve_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, partial, chunks, spp, inv_gamma, n_pixels, out_rgb8, out_f32);
+hipError_t launch_resolve(const RenderArgs& a, int local_tiles, hipStream_t stream) {
+    const size_t n = (size_t)local_tiles * (size_t)(a.frame.tile * a.frame.tile);          // upper bound; the kernel stops at sched[0] tiles
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(dsrt_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -526,6 +540,29 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
     const size_t n = (size_t)W * H;
     hipLaunchKernelGGL(dsrt_deinterleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, gathered, image, W, H, tile, tiles_x,
                        shard_count, shard_stride_bytes);
+    return hipGetLastError();
+}
+
+// 128-bit position-dependent content hash of a word array (the drop-in layer's "same scene as last frame?" test, device_api.hip):
+// two independent 64-bit mixes of (word, index, salt), summed -- addition commutes, so blocks may finish in any order.
+__global__ void __launch_bounds__(256) dsrt_content_hash_kernel(const uint32_t* __restrict__ words, size_t n, uint64_t salt, uint64_t* __restrict__ out2) {
+    uint64_t a = 0, b = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = ((uint64_t)words[i] << 32 | (uint64_t)(uint32_t)i) ^ salt ^ ((uint64_t)(i >> 32) * 0xD6E8FEB86659FD93ull);
+        x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+        a += x;
+        uint64_t y = x ^ 0xA0761D6478BD642Full;
+        y ^= y >> 29; y *= 0xBF58476D1CE4E5B9ull; y ^= y >> 32;
+        b += y * 0x94D049BB133111EBull;
+    }
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd((unsigned long long*)&out2[0], (unsigned long long)a); atomicAdd((unsigned long long*)&out2[1], (unsigned long long)b); }
+}
+
+hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream) {
+    if (!n_words) return hipSuccess;
+    const size_t want = (n_words + 255) / 256;
+    hipLaunchKernelGGL(dsrt_content_hash_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, words, n_words, salt, d_hash2);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct Builder {
 }  // namespace
 
 extern "C" int dsrt_host_scene_build_bvh(DsrtHostScene* hs) {
+    return dsrt::guarded("dsrt_host_scene_build_bvh", [&]() -> int {
     if (!hs) { dsrt::set_error("dsrt_host_scene_build_bvh: null scene"); return DSRT_ERR_INVALID; }
     hs->tri_indices.clear();
     hs->nodes.clear();
@@ -117,4 +118,5 @@ extern "C" int dsrt_host_scene_build_bvh(DsrtHostScene* hs) {
         return DSRT_ERR_BVH_DEPTH;
     }
     return DSRT_OK;
+    });
 }

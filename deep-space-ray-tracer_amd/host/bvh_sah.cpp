@@ -117,6 +117,7 @@ struct SahBuilder {
 }  // namespace
 
 extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
+    return dsrt::guarded("dsrt_host_scene_build_bvh_sah", [&]() -> int {
     if (!hs) { dsrt::set_error("dsrt_host_scene_build_bvh_sah: null scene"); return DSRT_ERR_INVALID; }
     hs->tri_indices.clear();
     hs->nodes.clear();
@@ -147,4 +148,5 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
         return DSRT_ERR_BVH_DEPTH;
     }
     return DSRT_OK;
+    });
 }

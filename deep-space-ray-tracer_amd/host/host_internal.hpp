@@ -2,6 +2,9 @@
 #pragma once
 
 #include <cstdint>
+#include <exception>
+#include <memory>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -11,6 +14,15 @@
 namespace dsrt {
 
 void set_error(const std::string& msg);
+
+// No exception crosses the C ABI: the bodies of the extern "C" entry points that allocate or parse run inside this.
+template <class F>
+int guarded(const char* where, F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { try { set_error(std::string(where) + ": out of memory"); } catch (...) {} return -8; /* DSRT_ERR_NOMEM */ }
+    catch (const std::exception& e) { try { set_error(std::string(where) + ": " + e.what()); } catch (...) {} return -1; /* DSRT_ERR_INVALID */ }
+    catch (...) { try { set_error(std::string(where) + ": unknown exception"); } catch (...) {} return -1; }
+}
 
 struct RgbImage {
     int width = 0, height = 0;

@@ -21,6 +21,11 @@ namespace dsrt {
 
 namespace {
 
+// Largest texture accepted (pixels).  Headers come from untrusted files: sizes are checked against this and against the
+// payload actually present before any buffer is sized from them.
+constexpr unsigned long long kMaxTexturePixels = 1ull << 28;
+
+
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
     std::ifstream in(path, std::ios::binary);
     if (!in) return false;
@@ -62,8 +67,14 @@ bool decode_pnm(const std::vector<uint8_t>& f, RgbImage& img) {
     int w, h, maxv;
     if (!c.number(w) || !c.number(h) || !c.number(maxv)) return false;
     if (w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) return false;
+    if ((unsigned long long)w * (unsigned long long)h > kMaxTexturePixels) return false;
     const int ch = (kind == 3 || kind == 6) ? 3 : 1;
     const size_t count = (size_t)w * h * ch;
+    {   // the payload must be able to fill the claimed size BEFORE anything is allocated for it
+        const size_t left = (size_t)(c.end - c.p);
+        const size_t need = (kind == 5 || kind == 6) ? count * (maxv > 255 ? 2 : 1) : (count ? 2 * count - 1 : 0);   // ASCII: a digit and a separator per sample
+        if (left < need) return false;
+    }
     std::vector<uint8_t> raw(count);
     if (kind == 5 || kind == 6) {
         if (c.p < c.end) ++c.p;                       // the single whitespace after maxval
@@ -116,6 +127,7 @@ bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
         pos += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || interlace != 0) return false;
+    if ((unsigned long long)w * (unsigned long long)h > kMaxTexturePixels) return false;
     int channels;
     switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
                      case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
@@ -123,6 +135,8 @@ bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
     const size_t bits_pp = (size_t)channels * depth;
     const size_t stride = (w * bits_pp + 7) / 8;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    // deflate expands by at most ~1032:1: an IDAT stream that cannot produce the claimed image is rejected before allocating
+    if ((unsigned long long)(stride + 1) * h > (unsigned long long)idat.size() * 1032ull + 1024ull) return false;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
@@ -199,6 +213,7 @@ extern "C" int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, i
 // PNG writer (8-bit RGB, filter 0, one zlib stream): the reference shells out to ImageMagick to turn its PPM into a PNG
 // (src/main.cpp:28-36); this is that step without the shell.
 extern "C" int dsrt_write_png(const char* path, const uint8_t* rgb, int width, int height) {
+    return dsrt::guarded("dsrt_write_png", [&]() -> int {
     if (!path || !rgb || width <= 0 || height <= 0) { dsrt::set_error("dsrt_write_png: bad argument"); return DSRT_ERR_INVALID; }
     const size_t row = (size_t)width * 3;
     std::vector<uint8_t> raw((row + 1) * (size_t)height);
@@ -234,4 +249,5 @@ extern "C" int dsrt_write_png(const char* path, const uint8_t* rgb, int width, i
     std::fclose(f);
     if (!ok) { dsrt::set_error(std::string("short write to ") + path); return DSRT_ERR_IO; }
     return DSRT_OK;
+    });
 }

@@ -72,6 +72,7 @@ D3 yaw_about_y(const D3& p, double yaw_deg) {
 extern "C" {
 
 int dsrt_read_pose_file(const char* path, DsrtPose* out, int cap, int* count) {
+    return dsrt::guarded("dsrt_read_pose_file", [&]() -> int {
     if (!path || !count || cap < 0 || (cap > 0 && !out)) { dsrt::set_error("dsrt_read_pose_file: bad argument"); return DSRT_ERR_INVALID; }
     *count = 0;
     std::ifstream in(path);
@@ -94,6 +95,7 @@ int dsrt_read_pose_file(const char* path, DsrtPose* out, int cap, int* count) {
     *count = n;
     if (n == 0) { dsrt::set_error(std::string("no valid pose in ") + path); return DSRT_ERR_IO; }
     return DSRT_OK;
+    });
 }
 
 int dsrt_pose_to_frame(const DsrtPose* pose, DsrtFrame* out) {

@@ -147,15 +147,18 @@ DsrtHostScene* dsrt_host_scene_create(void) { return new DsrtHostScene(); }
 void dsrt_host_scene_destroy(DsrtHostScene* hs) { delete hs; }
 
 int dsrt_host_scene_add_obj(DsrtHostScene* hs, const char* obj_path, double scale) {
+    return dsrt::guarded("dsrt_host_scene_add_obj", [&]() -> int {
     if (!hs || !obj_path) { set_error("dsrt_host_scene_add_obj: null argument"); return DSRT_ERR_INVALID; }
     auto fallback = std::make_shared<lambertian>(vec3(0.73f, 0.73f, 0.73f));      // src/main.cpp:240
     auto mesh = std::make_shared<triangle_mesh>(std::string(obj_path), fallback, scale);
     if (!mesh->loaded) { set_error(std::string("cannot open OBJ file ") + obj_path); return DSRT_ERR_IO; }
     hittable_list world(mesh);
     return flatten_world(world, hs);
+    });
 }
 
 int dsrt_host_scene_add_world_file(DsrtHostScene* hs, const char* world_path) {
+    return dsrt::guarded("dsrt_host_scene_add_world_file", [&]() -> int {
     if (!hs || !world_path) { set_error("dsrt_host_scene_add_world_file: null argument"); return DSRT_ERR_INVALID; }
     std::ifstream in(world_path);
     if (!in) { set_error(std::string("cannot open world file ") + world_path); return DSRT_ERR_IO; }
@@ -208,10 +211,12 @@ int dsrt_host_scene_add_world_file(DsrtHostScene* hs, const char* world_path) {
         }
     }
     return flatten_world(world, hs);
+    });
 }
 
 int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int num_tris, const GPUSphere* spheres, int num_spheres,
                                const GPUMaterial* mats, int num_mats) {
+    return dsrt::guarded("dsrt_host_scene_add_arrays", [&]() -> int {
     if (!hs || num_tris < 0 || num_spheres < 0 || num_mats < 0 || (num_tris && !tris) || (num_spheres && !spheres) || (num_mats && !mats)) {
         set_error("dsrt_host_scene_add_arrays: bad argument");
         return DSRT_ERR_INVALID;
@@ -224,6 +229,7 @@ int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int n
     for (int i = 0; i < num_spheres; ++i) { GPUSphere s = spheres[i]; s.material_id += base; hs->spheres.push_back(s); }
     hs->bvh_valid = false;
     return DSRT_OK;
+    });
 }
 
 int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out) {

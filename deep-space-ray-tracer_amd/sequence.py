@@ -1,0 +1,106 @@
+"""BASELINE.json configs[4] as one job: every pose of the file rendered once, the scene resident across frames.
+
+The reference's frame loop (src/main.cpp:310-431) rebuilds the BVH, re-uploads the whole scene and renders one frame at a time.
+Here only camera and sun change per frame (dsrt_scene_set_camera_sun) and `inflight` frames are in flight at once on one GPU,
+each on its own HIP stream with its own context (dsrt_ctx_clone: the contexts SHARE the resident scene, they differ in camera,
+queue words and scratch) and its own device + pinned host image.  Why several frames in flight: with the reference's one LCG
+stream per pixel a frame ends in a tail of a few spp-sample serial chains, and the next frames' workgroups fill the CUs that
+tail leaves idle.
+
+With more than one rank (one process per GPU, torch.distributed) the job splits one of two ways:
+  split="frames"  poses are dealt round-robin: rank r renders frames r, r + N, ... whole; no collective on the data path.  The
+                  natural shard of a sequence, and the only one that scales in rng_mode 0 (a pixel is a serial chain however many
+                  GPUs share its frame).
+  split="tiles"   every frame is sharded by interleaved screen tiles over all ranks and gathered to rank 0 (one gather per frame).
+"""
+import numpy as np
+
+
+def frame_assignment(frame_ids, rank, world, split):
+    """The frames this rank works on: all of them (tile split: every rank renders its tiles of every frame) or every world-th."""
+    frame_ids = list(frame_ids)
+    return frame_ids if split == "tiles" or world == 1 else frame_ids[rank::world]
+
+
+class FramePipeline:
+    """K frames in flight on one GPU.  `submit(i, camera, sun)` queues frame i on the next slot (waiting for that slot's previous
+    frame first); `drain()` waits for everything.  `on_frame(i, host_uint8_tensor)` is called when a frame's image has landed in
+    pinned host memory (the tensor is reused by later frames: copy it if you keep it)."""
+
+    def __init__(self, d, ctx, W, H, spp, depth, inflight=4, rng_mode=0, device=None, shard=None, on_frame=None):
+        import torch
+        self.torch, self.d = torch, d
+        self.W, self.H, self.spp, self.depth, self.rng_mode = W, H, spp, depth, rng_mode
+        self.dev = device if device is not None else torch.device("cuda", ctx.device)
+        self.K = max(1, int(inflight))
+        self.ctxs = [ctx] + [ctx.clone() for _ in range(1, self.K)]
+        with torch.cuda.device(self.dev):
+            self.streams = [torch.cuda.Stream() for _ in range(self.K)]
+        self.shard = shard                                            # None or (rank, world, gather_fn)
+        n_img = W * H * 3
+        if shard:
+            rank, world, _ = shard
+            lay = d.shard_layout(d.make_desc(W, H, spp, depth, shard_rank=rank, shard_count=world))
+            self.parts = [torch.zeros(lay["rgb8_bytes_padded"], dtype=torch.uint8, device=self.dev) for _ in range(self.K)]
+        root = (not shard) or shard[0] == 0
+        self.images = [torch.zeros(n_img, dtype=torch.uint8, device=self.dev) for _ in range(self.K)] if root else None
+        self.host = [torch.empty(n_img, dtype=torch.uint8).pin_memory() for _ in range(self.K)] if root else None
+        self.pending = [None] * self.K
+        self.on_frame = on_frame
+        self.n = 0
+
+    def _retire(self, slot):
+        if self.pending[slot] is not None:
+            self.streams[slot].synchronize()
+            if self.on_frame is not None and self.host is not None:
+                self.on_frame(self.pending[slot], self.host[slot])
+            self.pending[slot] = None
+
+    def submit(self, frame_index, camera, sun_dir):
+        torch, d = self.torch, self.d
+        slot = self.n % self.K
+        self.n += 1
+        self._retire(slot)
+        c, stream = self.ctxs[slot], self.streams[slot]
+        c.set_camera_sun(camera, tuple(sun_dir))
+        if self.shard:
+            rank, world, gather = self.shard
+            desc = d.make_desc(self.W, self.H, self.spp, self.depth, shard_rank=rank, shard_count=world, rng_mode=self.rng_mode)
+        else:
+            desc = d.make_desc(self.W, self.H, self.spp, self.depth, rng_mode=self.rng_mode)
+        with torch.cuda.stream(stream):                               # everything of this frame is ordered on its slot's stream
+            target = self.parts[slot] if self.shard else self.images[slot]
+            c.render(desc, target.data_ptr(), stream=stream.cuda_stream)
+            if self.shard:
+                flat = gather(self.parts[slot], world, rank)
+                if rank == 0:
+                    c.deinterleave(desc, flat.data_ptr(), self.images[slot].data_ptr(), stream=stream.cuda_stream)
+            if self.host is not None:
+                self.host[slot].copy_(self.images[slot], non_blocking=True)
+        self.pending[slot] = frame_index
+
+    def drain(self):
+        for k in range(self.K):
+            self._retire((self.n + k) % self.K)                       # oldest first: frames are handed over in submission order
+
+    def close(self):
+        self.drain()
+        for c in self.ctxs[1:]:
+            c.close()
+        self.ctxs = self.ctxs[:1]
+
+
+def render_frames(d, ctx, hs_frame, frame_ids, W, H, spp, depth, inflight=4, rng_mode=0, keep=True):
+    """Convenience for tests and tools: render `frame_ids` through a FramePipeline on ctx's GPU; `hs_frame(i)` returns
+    (camera, sun_dir) of frame i.  Returns {frame id: H x W x 3 uint8 array} (or {} with keep=False)."""
+    out = {}
+
+    def got(i, host):
+        if keep:
+            out[i] = host.numpy().reshape(H, W, 3).copy()
+    pipe = FramePipeline(d, ctx, W, H, spp, depth, inflight=inflight, rng_mode=rng_mode, on_frame=got)
+    for i in frame_ids:
+        cam, sun = hs_frame(i)
+        pipe.submit(i, cam, sun)
+    pipe.close()
+    return out

@@ -28,6 +28,8 @@ extern "C" {
 #define DSRT_ERR_BVH_DEPTH   -5   /* BVH deeper than the 64-entry stack of src/gpu_render.cu:399 */
 #define DSRT_ERR_NO_SCENE    -6   /* render before upload                                      */
 #define DSRT_ERR_DEVICE_FLAG -7   /* the kernel raised its checked-mode status word            */
+#define DSRT_ERR_NOMEM       -8   /* host allocation failed (no C++ exception crosses this ABI) */
+#define DSRT_ERR_COMM        -9   /* an RCCL call failed                                         */
 
 const char* dsrt_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
@@ -119,6 +121,13 @@ int  dsrt_device_count(void);
 int  dsrt_ctx_create(int device, DsrtContext** out);
 void dsrt_ctx_destroy(DsrtContext* ctx);
 
+/* A second context on the same device that SHARES `src`'s resident scene (no copy, no re-upload) and has its own camera / sun
+ * and its own working buffers: what a host needs to keep several frames of one scene in flight on separate streams.  A context
+ * serves one render at a time (a second dsrt_render on it waits for the first, on any stream).  Uploading a new scene into
+ * either context afterwards does not affect the other.  No reference counterpart (the reference renders one frame at a time). */
+int  dsrt_ctx_clone(const DsrtContext* src, DsrtContext** out);
+int  dsrt_ctx_device(const DsrtContext* ctx);
+
 /* Upload + re-layout for the GPU (once per scene, not per frame).  `scene` holds HOST pointers in the
  * reference layouts (as from dsrt_host_scene_view); its camera/params/sun are recorded as the current frame.
  * Replaces the upload half of build_gpu_scene (src/gpu_scene_builder.cpp:322-331, 475-546). */
@@ -200,6 +209,43 @@ int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float*
 /* Device check that the kernel's stateless Philox4x32-10 equals rocRAND's engine: the first n 32-bit words of
  * (seed, subsequence, offset 0) from both.  Host pointers. */
 int dsrt_selftest_philox(DsrtContext* ctx, uint64_t seed, uint64_t subsequence, int n, uint32_t* ours, uint32_t* rocrand_words);
+
+/* ===================================================================================== */
+/* All GPUs of a node from ONE host process (the reference's main() is one process calling */
+/* gpu_render_scene per frame, src/main.cpp:310-431; it has no multi-GPU code).           */
+/* ===================================================================================== */
+typedef struct DsrtMulti DsrtMulti;
+
+/* `devices[r]` is the HIP device of rank r.  Distinct devices: an RCCL communicator is created over them (ncclCommInitAll).
+ * Ranks that share a device (a one-GPU box: tests) get the same code path with the gather done by device-to-device copies --
+ * RCCL refuses duplicate devices.  `frames_in_flight` (>= 1) is used by dsrt_multi_render_sequence only. */
+int  dsrt_multi_create(const int* devices, int n, int frames_in_flight, DsrtMulti** out);
+void dsrt_multi_destroy(DsrtMulti* m);
+int  dsrt_multi_count(const DsrtMulti* m);
+int  dsrt_multi_uses_rccl(const DsrtMulti* m);
+/* The scene (HOST pointers, reference layouts) is converted and made resident once per device. */
+int  dsrt_multi_scene_upload(DsrtMulti* m, const GPUScene* host_scene);
+/* ONE frame over all ranks: interleaved screen tiles (tile g -> rank g mod N), one ncclGather of the equal-sized compact
+ * buffers to rank 0, de-interleave there, image (width*height*3, top row first) copied to `h_rgb8` (host).  desc's shard fields
+ * are ignored.  Optional outputs: per-rank render time in ms (HIP events; N floats) and the wall time of the whole call. */
+int  dsrt_multi_render_frame(DsrtMulti* m, const DsrtRenderDesc* desc, const GPUCamera* cam, const float sun_dir_model[3],
+                             uint8_t* h_rgb8, float* kernel_ms_per_rank, double* seconds);
+/* MANY frames of the resident scene (src/main.cpp's frame loop): frame i is rendered WHOLE by rank i mod N -- no collective --
+ * with `frames_in_flight` frames going per rank on separate streams.  cams[i] / sun_dirs[3 i ..] as from dsrt_camera_look_at /
+ * dsrt_pose_to_frame.  h_images may be NULL (timing only) or hold n_frames host pointers (NULL entries are skipped). */
+int  dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc, const GPUCamera* cams, const float* sun_dirs, int n_frames,
+                                uint8_t* const* h_images, double* seconds);
+
+/* Calibration of the roofline the render kernel is measured against (bench.py): a kernel with the render
+ * kernel's launch shape (256-thread workgroups, 4 waves per SIMD, grid = resident set) in which `live_lanes` of every 64 lanes gather
+ * random aligned 64-byte records from a table of `table_bytes` bytes, `iters` records per lane, and do nothing else.
+ *   mode 0: each lane reads its record as 4 x 16-byte loads (the render kernel's access shape)
+ *   mode 1: the four lanes of a quad read one record per load instruction into an LDS tile (global_load_lds_dwordx4), 4 x ds_read_b128 back
+ *   mode 2: as 1 through registers (global_load_dwordx4 + ds_write_b128)
+ * dependent != 0: the next record index depends on the loaded data (a traversal step); pad_valu: dependent v_fma per record.
+ * Returns the kernel time (HIP events) and the number of records gathered.  No reference interface: measurement only. */
+int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, int pad_valu, size_t table_bytes, int iters,
+                           float* out_ms, double* out_records);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

@@ -585,6 +585,24 @@ int dsrt_oracle_bbox_hit(const float lo[3], const float hi[3], const float orig[
     return bbox_hit(&n, &r, t_min, t_max, &c);
 }
 
+/* Test hooks for the known-answer vectors of the reference's device helpers (tests/golden/ref_devkat.json). */
+void dsrt_oracle_random_in_unit_sphere(uint32_t* state, float out[3]) {
+    DsrtOracleCounters c; memset(&c, 0, sizeof c);
+    Rng g = { *state, &c };
+    V3 p = random_in_unit_sphere(&g);
+    *state = g.state; out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+void dsrt_oracle_random_cosine_direction(uint32_t* state, float out[3]) {
+    DsrtOracleCounters c; memset(&c, 0, sizeof c);
+    Rng g = { *state, &c };
+    V3 p = random_cosine_direction(&g);
+    *state = g.state; out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+void dsrt_oracle_camera_ray(const GPUCamera* cam, int px, int py, int W, int H, float jx, float jy, float orig[3], float dir[3]) {
+    Ray r = camera_ray(cam, px, py, W, H, jx, jy);
+    orig[0] = r.orig.x; orig[1] = r.orig.y; orig[2] = r.orig.z; dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
+}
+
 float dsrt_oracle_sinf(float x) { return dsrt_sinf(x); }
 float dsrt_oracle_cosf(float x) { return dsrt_cosf(x); }
 float dsrt_oracle_powf(float x, float y) { return dsrt_powf(x, y); }

@@ -75,6 +75,12 @@ int dsrt_oracle_scene_hit(const GPUScene* scene, const float orig[3], const floa
 int dsrt_oracle_bbox_hit(const float lo[3], const float hi[3], const float orig[3], const float dir[3], float t_min, float t_max);
 
 /* The shared deterministic math, exposed so tests can compare device results bit for bit. */
+/* The oracle's rejection loop (:82-91), cosine direction in local coordinates (:99-109) and camera ray (:941-968) on their own,
+ * for the known-answer vectors produced by the reference's host-compilable device helpers (tests/golden/ref_devkat.json). */
+void dsrt_oracle_random_in_unit_sphere(uint32_t* state, float out[3]);
+void dsrt_oracle_random_cosine_direction(uint32_t* state, float out[3]);
+void dsrt_oracle_camera_ray(const GPUCamera* cam, int px, int py, int W, int H, float jx, float jy, float orig[3], float dir[3]);
+
 float dsrt_oracle_sinf(float x);
 float dsrt_oracle_cosf(float x);
 float dsrt_oracle_powf(float x, float y);

@@ -232,10 +232,59 @@ static int cmd_hitkat(int n) {
     return 0;
 }
 
+// Known answers from the reference's own DEVICE helpers, which compile on the host (CUDA_D is empty off nvcc, inc/cuda_compat.h):
+//   random_float_device              inc/rtweekend.h:126-133   the LCG (same constants as src/gpu_render.cu:77-80)
+//   random_in_unit_sphere_device     :164-171                  the rejection loop (candidates -1 + 2 r: exact in float and in double)
+//   random_cosine_direction_device   :190-202                  cosine direction in local coordinates, DOUBLE math rounded to float
+//   generate_camera_ray_device       inc/camera.h:35-61        ray set-up, lens_radius = 0
+// The kernel does not call these (it has its own float copies, src/gpu_render.cu:77-109, 941-968), but they are the
+// same formulas executed by reference code, which is what the oracle's rand01 / rejection loop / cosine direction / camera ray can be
+// pinned against: bit for bit where the arithmetic is float or exact, to rounding where the reference helper computes in double.
+static int cmd_devkat(int n) {
+    std::printf("{\"lcg\": [\n");
+    const uint32_t seeds[4] = {1337u, 0u, 0xFFFFFFFFu, 123456789u};
+    for (int k = 0; k < 4; ++k) {
+        uint32_t s = seeds[k];
+        std::printf("  {\"seed\": %u, \"draws\": [", seeds[k]);
+        for (int i = 0; i < 16; ++i) { float f = random_float_device(s); std::printf("[%u, %u]%s", s, fbits(f), i < 15 ? ", " : ""); }
+        std::printf("]}%s\n", k < 3 ? "," : "");
+    }
+    std::printf("],\n\"unit_sphere\": [\n");
+    for (int i = 0; i < n; ++i) {
+        uint32_t s0 = 1000003u * (uint32_t)i + 17u, s = s0;
+        vec3 p = random_in_unit_sphere_device(s);
+        std::printf("  {\"state_in\": %u, \"state_out\": %u, \"p\": [%u, %u, %u]}%s\n", s0, s, fbits(p.x()), fbits(p.y()), fbits(p.z()), i + 1 < n ? "," : "");
+    }
+    std::printf("],\n\"cosine_direction\": [\n");
+    for (int i = 0; i < n; ++i) {
+        uint32_t s0 = 7919u * (uint32_t)i + 5u, s = s0;
+        vec3 d = random_cosine_direction_device(s);
+        std::printf("  {\"state_in\": %u, \"state_out\": %u, \"d\": [%u, %u, %u]}%s\n", s0, s, fbits(d.x()), fbits(d.y()), fbits(d.z()), i + 1 < n ? "," : "");
+    }
+    std::printf("],\n\"camera_ray\": [\n");
+    camera cam;
+    cam.image_width = 200; cam.image_height = 112; cam.samples_per_pixel = 4; cam.max_depth = 5; cam.vfov = 40; cam.aperture = 0.0;
+    point_camera_at(cam, vec3(-0.72611237f, 0.0f, 1786.9741f), vec3(0, 0, 0));
+    const GPUCamera g = cam.toGPUCamera();
+    std::printf("  {\"camera\": \""); hex_bytes(&g, sizeof g); std::printf("\", \"rays\": [\n");
+    for (int i = 0; i < n; ++i) {
+        uint32_t s0 = 2654435761u * (uint32_t)(i + 1), s = s0;
+        const int px = (i * 37) % 200, py = (i * 11) % 112;
+        uint32_t sj = s0;
+        const float jx = (float)random_double_device(sj), jy = (float)random_double_device(sj);      // the jitter the helper is about to draw
+        ray r = generate_camera_ray_device(g, px, py, s);
+        std::printf("    {\"px\": %d, \"py\": %d, \"state_in\": %u, \"state_out\": %u, \"jx\": %u, \"jy\": %u, \"orig\": [%u, %u, %u], \"dir\": [%u, %u, %u]}%s\n",
+                    px, py, s0, s, fbits(jx), fbits(jy), fbits(r.origin().x()), fbits(r.origin().y()), fbits(r.origin().z()),
+                    fbits(r.direction().x()), fbits(r.direction().y()), fbits(r.direction().z()), i + 1 < n ? "," : "");
+    }
+    std::printf("  ]}\n]}\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: ref_host abi | scene <world.txt> <prefix> | camera fx fy fz ax ay az vfov W H spp depth |"
-                             " poses <pose.txt> W H spp depth vfov | hitkat <n>\n");
+                             " poses <pose.txt> W H spp depth vfov | hitkat <n> | devkat <n>\n");
         return 2;
     }
     std::string c = argv[1];
@@ -244,5 +293,6 @@ int main(int argc, char** argv) {
     if (c == "camera") return cmd_camera(argc, argv);
     if (c == "poses") return cmd_poses(argc, argv);
     if (c == "hitkat" && argc >= 3) return cmd_hitkat(std::atoi(argv[2]));
+    if (c == "devkat" && argc >= 3) return cmd_devkat(std::atoi(argv[2]));
     return 2;
 }

@@ -183,6 +183,8 @@ def main():
     json.dump(run_ref("abi"), open(os.path.join(HERE, "ref_abi.json"), "w"), indent=1)
     json.dump(run_ref("poses", POSE_FILE, 640, 360, 64, 50, 40), open(os.path.join(HERE, "ref_poses_640x360.json"), "w"))
     json.dump(run_ref("hitkat", 240), open(os.path.join(HERE, "ref_hitkat.json"), "w"))
+    # the reference's host-compilable DEVICE helpers (inc/rtweekend.h:126-202, inc/camera.h:35-61): LCG, rejection loop, cosine direction, camera ray
+    json.dump(run_ref("devkat", 96), open(os.path.join(HERE, "ref_devkat.json"), "w"))
     cams = []
     for spec in ((-2, 2, 1, 0, 0, -1, 20, 200, 112, 16, 50), (0, 0, 60, 0, 0, 0, 40, 640, 360, 64, 50), (13, 2, 3, 0, 0, -1, 20, 1920, 1080, 1000, 50),
                  (0, 3, 9, 0, 2, 0, 45, 200, 112, 16, 12), (0, 40, 0.001, 0, 0, 0, 35, 320, 240, 4, 5)):

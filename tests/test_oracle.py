@@ -167,3 +167,58 @@ def test_book_style_baseline_runs_on_c1(tmp_path):
     r2 = subprocess.run([exe, "c1_spheres.world", "100", "56", "4", "50", "1", "-2", "2", "1", "0", "0", "-1", "20", "0.3", "-0.8", "0.5", "-", "10", "20"],
                         cwd=ASSETS, stdout=subprocess.PIPE, text=True, check=True)
     assert json.loads(r2.stdout)["samples"] == 100 * 10 * 4
+
+
+def test_device_helper_known_answers_from_the_reference(oracle):
+    """tests/golden/ref_devkat.json comes from the reference's own host-compilable device helpers, executed (oracle/ref_host_driver.cpp
+    `devkat`): random_float_device (inc/rtweekend.h:126-133), random_in_unit_sphere_device (:164-171), random_cosine_direction_device
+    (:190-202), generate_camera_ray_device with lens_radius 0 (inc/camera.h:35-61).  The kernel has float copies of the same formulas
+    (src/gpu_render.cu:77-109, 941-968) which the oracle restates.  Exact where the arithmetic is float or exact (LCG, rejection loop,
+    camera ray); to rounding where the helper works in double (cosine direction: cos/sin/sqrt in double rounded once vs the oracle's
+    float sqrt and shared deterministic sin/cos).  What stays unpinned after this: ray_color's control flow and the traversal order."""
+    kat = json.load(open(os.path.join(GOLDEN, "ref_devkat.json")))
+    L = oracle.lib
+    for fn in (L.dsrt_oracle_random_in_unit_sphere, L.dsrt_oracle_random_cosine_direction):
+        fn.restype = None
+        fn.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+    L.dsrt_oracle_camera_ray.restype = None
+    L.dsrt_oracle_camera_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    bits = lambda arr: [struct.unpack("<I", struct.pack("<f", v))[0] for v in arr]            # noqa: E731
+    # LCG: state sequence and the float, bit for bit, from four seeds (incl. the wrap-around ones)
+    for row in kat["lcg"]:
+        s = C.c_uint32(row["seed"])
+        for state, fbits in row["draws"]:
+            v = L.dsrt_oracle_rand01(C.byref(s))
+            assert s.value == state and bits([v])[0] == fbits
+    assert kat["lcg"][0]["draws"][0][0] == 0xC114ED44                    # the known answer SURVEY.md section 8(a2) quotes
+    # rejection loop: same number of draws (final state) and the same point, bit for bit
+    loops = 0
+    for row in kat["unit_sphere"]:
+        s, out = C.c_uint32(row["state_in"]), (C.c_float * 3)()
+        L.dsrt_oracle_random_in_unit_sphere(C.byref(s), out)
+        # random_vec3_device builds vec3(draw, draw, draw): the order in which a compiler evaluates the three arguments is unspecified and
+        # g++ (which built oracle/_ref) goes right to left, so the helper's x is the THIRD draw.  The kernel's own copy
+        # (src/gpu_render.cu:82-91, what the oracle restates) draws x, y, z in statement order.  Same three values, same accept/reject.
+        assert s.value == row["state_out"] and bits(out)[::-1] == row["p"]
+        t = C.c_uint32(row["state_in"])
+        for _ in range(3):
+            L.dsrt_oracle_rand01(C.byref(t))
+        loops += t.value != row["state_out"]
+    assert loops > 10                                                     # the vectors do exercise rejections (48 % of candidates are outside)
+    # cosine direction: two draws, z exact (sqrt of an exact float difference), x / y to float rounding of double math
+    worst = 0.0
+    for row in kat["cosine_direction"]:
+        s, out = C.c_uint32(row["state_in"]), (C.c_float * 3)()
+        L.dsrt_oracle_random_cosine_direction(C.byref(s), out)
+        assert s.value == row["state_out"]
+        ref = [f32(b) for b in row["d"]]
+        assert bits([out[2]])[0] == row["d"][2]
+        worst = max(worst, abs(out[0] - ref[0]), abs(out[1] - ref[1]))
+    assert worst <= 4e-7, worst                                           # |x|, |y| <= 1: a few float ulps
+    # camera ray (frame 0 camera of the pose file, 200 x 112): direction and origin bit for bit given the helper's own jitter
+    cam_rec = kat["camera_ray"][0]
+    cam = (C.c_char * 104).from_buffer_copy(bytes.fromhex(cam_rec["camera"]))
+    for row in cam_rec["rays"]:
+        o, d = (C.c_float * 3)(), (C.c_float * 3)()
+        L.dsrt_oracle_camera_ray(C.byref(cam), row["px"], row["py"], 200, 112, f32(row["jx"]), f32(row["jy"]), o, d)
+        assert bits(o) == row["orig"] and bits(d) == row["dir"], row
