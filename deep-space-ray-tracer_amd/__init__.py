@@ -75,15 +75,26 @@ class HostScene:
         return self
 
     def build_bvh(self, kind="median"):
-        """kind "median": the reference's tree (parity); "sah": binned-SAH tree, non-parity fast mode (include/dsrt.h)."""
+        """kind "median": the reference's tree (parity); "sah": binned-SAH tree, "lbvh": linear BVH built on the GPU -- non-parity fast modes."""
         if kind == "median":
             _check(lib.dsrt_host_scene_build_bvh(self._h), "dsrt_host_scene_build_bvh")
         elif kind == "sah":
             _check(lib.dsrt_host_scene_build_bvh_sah(self._h), "dsrt_host_scene_build_bvh_sah")
+        elif kind == "lbvh":                         # built on the GPU (device 0 unless set_lbvh_device says otherwise)
+            ms, tot = C.c_float(), C.c_float()
+            _check(lib.dsrt_host_scene_build_bvh_gpu(self._h, int(getattr(self, "lbvh_device", 0)), C.byref(ms), C.byref(tot)), "dsrt_host_scene_build_bvh_gpu")
+            self.lbvh_build_ms, self.lbvh_total_ms = ms.value, tot.value
         else:
-            raise ValueError("build_bvh kind must be 'median' or 'sah'")
+            raise ValueError("build_bvh kind must be 'median', 'sah' or 'lbvh'")
         self._built = True
         return self
+
+    @property
+    def texture_failures(self):
+        """Paths of texture maps that could not be decoded (their texel is the reference's 1x1 white fallback)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.dsrt_host_scene_texture_failures(self._h, buf, len(buf))
+        return [p for p in buf.value.decode(errors="replace").split("\n") if p][:n] if n else []
 
     @property
     def stack_need(self):

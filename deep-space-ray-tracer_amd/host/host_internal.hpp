@@ -47,6 +47,7 @@ struct DsrtHostScene {
 
     std::unordered_map<const dsrt::material*, int> mat_index;      // material object -> table slot
     std::unordered_map<std::string, int> tex_index;                // texture path -> header slot
+    std::vector<std::string> tex_failed;                           // paths that could not be decoded (their slot is the reference's 1x1 white)
     std::vector<std::shared_ptr<dsrt::material>> keep_alive;       // keeps mat_index keys unique for the scene's lifetime
     bool bvh_valid = false;
     int bvh_height = 0;                                            // levels; the traversal stack needs height - 1 entries

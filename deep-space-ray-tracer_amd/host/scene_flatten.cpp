@@ -60,6 +60,7 @@ int texture_slot(DsrtHostScene& hs, const std::string& path) {
     RgbImage img;
     if (!load_rgb8(path, texture_flip_latch(), img)) {
         std::fprintf(stderr, "WARN: failed to load texture '%s'\n", path.c_str());
+        hs.tex_failed.push_back(path);
         h.width = h.height = 1;
         hs.tex_pool.insert(hs.tex_pool.end(), {1.0f, 1.0f, 1.0f});
     } else {
@@ -251,6 +252,22 @@ int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out) {
     out->texture_pool = hs->tex_pool.empty() ? nullptr : hs->tex_pool.data();
     out->texture_pool_floats = (int)hs->tex_pool.size();
     return DSRT_OK;
+}
+
+int dsrt_host_scene_texture_failures(const DsrtHostScene* hs, char* names, size_t cap) {
+    if (!hs) return 0;
+    if (names && cap) {
+        size_t at = 0;
+        names[0] = 0;
+        for (const std::string& p : hs->tex_failed) {
+            if (at + p.size() + 2 > cap) break;
+            std::memcpy(names + at, p.data(), p.size());
+            at += p.size();
+            names[at++] = '\n';
+            names[at] = 0;
+        }
+    }
+    return (int)hs->tex_failed.size();
 }
 
 int dsrt_host_scene_bvh_stack_need(const DsrtHostScene* hs) {

@@ -26,7 +26,7 @@ static int fail(const char* what) {
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
     int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0;
-    bool sah = false, png = false;
+    bool sah = false, png = false, strict_textures = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* {
@@ -45,9 +45,10 @@ int main(int argc, char** argv) {
         else if (a == "--fast") { sah = true; rng_mode = 1; }      // non-parity fast mode: SAH tree + Philox stream per sample (include/dsrt.h)
         else if (a == "--bvh") sah = std::string(next("--bvh")) == "sah";
         else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
+        else if (a == "--strict-textures") strict_textures = true;  // refuse a mesh whose texture maps this library cannot decode (include/dsrt.h)
         else if (a == "--png") png = true;                          // frames as PNG instead of PPM (the reference converts with ImageMagick)
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast] [--png]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast] [--png] [--strict-textures]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -72,6 +73,15 @@ int main(int argc, char** argv) {
 
     DsrtHostScene* hs = dsrt_host_scene_create();
     if (dsrt_host_scene_add_obj(hs, obj.c_str(), 1.0) != DSRT_OK) return fail("loading the mesh");
+    {
+        char names[4096];
+        const int bad = dsrt_host_scene_texture_failures(hs, names, sizeof names);
+        if (bad) {
+            std::fprintf(stderr, "dsrt_render: %d texture map(s) could not be decoded (PNM and non-interlaced PNG only; the reference's stb_image also reads JPEG/BMP/TGA...);\n"
+                                 "they render as the reference's 1x1 white fallback, i.e. NOT like the reference would:\n%s", bad, names);
+            if (strict_textures) return 3;
+        }
+    }
     if ((sah ? dsrt_host_scene_build_bvh_sah(hs) : dsrt_host_scene_build_bvh(hs)) != DSRT_OK) return fail("building the BVH");
     GPUScene scene;
     if (dsrt_host_scene_view(hs, &scene) != DSRT_OK) return fail("viewing the scene");

@@ -70,9 +70,23 @@ int dsrt_host_scene_build_bvh(DsrtHostScene* hs);
  * reference interface this replaces -- the reference has one builder (src/gpu_scene_builder.cpp:343-459). */
 int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs);
 
+/* NOT the reference's tree either: a linear BVH (Morton order + Karras' radix-tree construction) built ON THE GPU `device`, in the same
+ * node format (leaf <= 4), copied into the host scene.  The "GPU-side BVH build" of SURVEY.md 8(f) n4: milliseconds instead of the
+ * seconds of the host builders, for hosts that rebuild per frame as the reference does (src/main.cpp:405).  Same parity status as the
+ * SAH tree: a statistically equivalent image, exact agreement between the kernel and the oracle on this tree.  `build_ms` (optional)
+ * receives the device time of the construction kernels, `total_ms` the whole call including the triangle upload and the copy back. */
+int dsrt_host_scene_build_bvh_gpu(DsrtHostScene* hs, int device, float* build_ms, float* total_ms);
+
 /* Fill `out` with HOST pointers into the scene's arrays (valid until the scene is modified or
  * destroyed).  Camera / params / sun fields of `out` are zeroed; set them with dsrt_scene_set_frame. */
 int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out);
+
+/* Textures that could not be decoded while objects were added.  Like the reference (stbi_load failure, src/gpu_scene_builder.cpp:216-221)
+ * the builder goes on with a 1x1 white texel for such a map and prints a warning -- but the reference's stb_image decodes JPEG, BMP,
+ * TGA, GIF, PSD, HDR, PIC and interlaced PNG, while this library decodes PNM and non-interlaced PNG only.  A scene for which this returns
+ * non-zero therefore does NOT render like the reference would; hosts that care should refuse it (dsrt_render --strict-textures does,
+ * bench.py labels the run).  Returns the number of failed maps; if `names` is given, their paths, newline-separated, as far as `cap` allows. */
+int dsrt_host_scene_texture_failures(const DsrtHostScene* hs, char* names, size_t cap);
 
 /* Greatest number of entries the reference traversal's stack can hold for this BVH (= height - 1). */
 int dsrt_host_scene_bvh_stack_need(const DsrtHostScene* hs);

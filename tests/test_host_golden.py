@@ -137,3 +137,20 @@ def test_png_writer(dsrt, tmp_path):
     assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(37, 53, 3), rgb)
     with pytest.raises(RuntimeError):
         dsrt.write_png(tmp_path / "no_such_dir" / "o.png", rgb, 53, 37)
+
+
+def test_undecodable_texture_is_reported_not_silently_white(dsrt, tmp_path):
+    """The reference's stb_image reads JPEG; this library reads PNM and non-interlaced PNG.  A map it cannot decode becomes the reference's
+    own failure fallback (1x1 white, src/gpu_scene_builder.cpp:216-221) AND is reported through the C ABI, so a host can refuse the scene."""
+    (tmp_path / "panel.jpg").write_bytes(bytes.fromhex("ffd8ffe000104a46494600010100000100010000ffd9"))      # a JFIF shell, no image
+    (tmp_path / "m.mtl").write_text("newmtl skin\nKd 0.5 0.4 0.3\nmap_Kd panel.jpg\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl skin\nf 1/1 2/2 3/3\n")
+    hs = dsrt.HostScene().add_obj(tmp_path / "m.obj")
+    hs.build_bvh()
+    bad = hs.texture_failures
+    assert len(bad) == 1 and bad[0].endswith("panel.jpg")
+    a = hs.arrays()
+    assert a["texhdr"].size == 1 and tuple(a["texhdr"][0]) [:2] == (1, 1) and np.array_equal(a["texpool"], np.float32([1, 1, 1]))
+    assert a["tris"]["albedo_tex"][0] == 0
+    ok = dsrt.HostScene().add_obj(os.path.join(ASSETS, "textured.obj"))
+    assert [os.path.basename(p) for p in ok.texture_failures] == ["does_not_exist.png"]       # the asset's deliberately missing map; its two real maps decode

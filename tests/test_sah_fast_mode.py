@@ -89,3 +89,48 @@ def test_kernel_on_sah_tree_matches_oracle_on_sah_tree(dsrt, gpu_ctx, oracle, na
         assert getattr(st, key) == want_cnt[key], key
     rgb2, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth))
     assert np.array_equal(rgb2, want_rgb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["station_near", "mixed", "textured"])
+def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(dsrt, gpu_ctx, oracle, name):
+    """dsrt_host_scene_build_bvh_gpu (csrc/bvh_lbvh.hip): the tree comes back in the reference's node format -- every triangle in exactly
+    one leaf of <= 4, child boxes inside parents, leaf boxes tight -- the oracle's image on it is the median tree's image up to
+    de-synchronised pixels, and the kernel on it equals the oracle on it bit for bit, counters included."""
+    hs, scene, W, H, spp, depth = _scene(dsrt, name, "lbvh")
+    assert hs.lbvh_build_ms > 0 and hs.lbvh_total_ms >= hs.lbvh_build_ms
+    a = hs.arrays()
+    nodes, idx, tris = a["nodes"], a["idx"], a["tris"]
+    assert sorted(idx.tolist()) == list(range(len(tris)))
+    verts = tris["v"]
+    covered, seen, todo = np.zeros(len(tris), bool), set(), [(0, None)]
+    while todo:
+        n, parent = todo.pop()
+        assert n not in seen
+        seen.add(n)
+        nd = nodes[n]
+        if parent is not None:
+            assert (nd["bbox_min"] >= nodes[parent]["bbox_min"]).all() and (nd["bbox_max"] <= nodes[parent]["bbox_max"]).all()
+        if nd["tri_count"] > 0:
+            assert nd["left"] == -1 and nd["right"] == -1 and nd["tri_count"] <= 4
+            sl = idx[nd["tri_offset"]:nd["tri_offset"] + nd["tri_count"]]
+            assert not covered[sl].any()
+            covered[sl] = True
+            v = verts[sl].reshape(-1, 3)
+            assert np.array_equal(v.min(axis=0), nd["bbox_min"]) and np.array_equal(v.max(axis=0), nd["bbox_max"])
+        else:
+            todo += [(int(nd["right"]), n), (int(nd["left"]), n)]
+    assert covered.all() and len(seen) == len(nodes) and hs.stack_need <= 64
+    want_rgb, want_f32, want_cnt = oracle.render(scene, W, H)
+    gpu_ctx.upload(scene)
+    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=2), want_f32=True)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32))
+    for key in ("rays", "box_fetches", "nodes_entered", "tri_tests", "hit_updates", "max_stack"):
+        assert getattr(st, key) == want_cnt[key], key
+    hs_m, scene_m, _, _, _, _ = _scene(dsrt, name, "median")
+    med, _, _ = oracle.render(scene_m, W, H)
+    assert (med != want_rgb).any(axis=2).mean() < 0.03 and abs(med.astype(float).mean() - want_rgb.astype(float).mean()) < 0.6
+    # deterministic: the same tree twice
+    hs2, _, _, _, _, _ = _scene(dsrt, name, "lbvh")
+    b = hs2.arrays()
+    assert np.array_equal(b["idx"], idx) and b["nodes"].tobytes() == nodes.tobytes()
