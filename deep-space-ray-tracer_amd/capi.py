@@ -134,7 +134,7 @@ def load():
     sig("dsrt_host_scene_add_world_file", C.c_int, [vp, C.c_char_p])
     sig("dsrt_host_scene_add_arrays", C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int])
     sig("dsrt_host_scene_build_bvh", C.c_int, [vp])
-    sig("dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", C.c_int, [vp])
+    sig("dsrt_host_scene_build_bvh_sah", C.c_int, [vp])
     sig("dsrt_host_scene_build_bvh_gpu", C.c_int, [vp, C.c_int, P(C.c_float), P(C.c_float)])
     sig("dsrt_host_scene_view", C.c_int, [vp, P(GPUScene)])
     sig("dsrt_host_scene_bvh_stack_need", C.c_int, [vp])
