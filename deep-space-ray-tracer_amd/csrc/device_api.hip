@@ -24,7 +24,7 @@
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
-hipError_t launch_resolve(const RenderArgs& a, int local_tiles, hipStream_t stream);
+hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
                                size_t shard_stride_bytes, hipStream_t stream);
@@ -255,7 +255,7 @@ struct DsrtContext {
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp;
-    DevBuf<float> partial;
+    DevBuf<unsigned long long> accum_fixed;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t done = nullptr;      // recorded behind every render: the next render on ANY stream waits for it (queue words, spill strip,
     bool done_valid = false;        // pre-pass arrays and partial sums are per context, so a context has one render in flight)
@@ -447,19 +447,23 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     f.chunks = 1; f.chunk_len = f.spp;
     const size_t out_pixels = desc->shard_count > 1 ? (size_t)t.padded * t.tile * t.tile : (size_t)desc->width * desc->height;
     if (desc->rng_mode == 1) {
-        // a pixel's samples are independent streams: split them into up to 16 work items per pixel
-        // 16 slices: with 32/64/128 the many short work items cost more in half-empty advance passes than the shorter tail saves
-        // (1080p x 1000, near frame: 1142 / 1177 / 1693 ms against 1139; profiles/r01/README.md)
-        f.chunk_len = f.spp < 128 ? (f.spp + 7) / 8 : (f.spp + 15) / 16;
+        // a pixel's samples are independent streams: pixels of tiles that see geometry are split into 8 work items.  More slices cost
+        // more in half-empty advance passes than their shorter tail saves; fewer leave whole waves without work at the end of a small
+        // job, which sample stealing (inside a wave, path_machine.h) cannot repair.  One rank's share of an 8-GPU 1080p x 1000 frame,
+        // stealing on: 1 / 2 / 4 / 8 / 16 / 32 / 64 slices = 307 / 289 / 188 / 171 / 181 / 191 / 203 ms; whole frame on one GPU
+        // 1091 / 1076 / 1063 / 1050 / 1047 (profiles/r02/README.md).  An item's integer sums are 32-bit in units of 2^-20: at most 4095
+        // samples per item, so with more samples than that every pixel is sliced, whatever its tile sees.
+        f.chunk_len = (f.spp + 7) / 8;
+        if ((desc->tune[3] >> 8) & 0xFFF) f.chunk_len = (f.spp + ((desc->tune[3] >> 8) & 0xFFF) - 1) / ((desc->tune[3] >> 8) & 0xFFF);   // experiments: slices per pixel
         if (f.chunk_len < 1) f.chunk_len = 1;
+        if (f.chunk_len > 4095) f.chunk_len = 4095;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
         if ((unsigned long long)f.total_items * (unsigned long long)f.chunks >= (1ull << 32)) { set_error("dsrt_render: image too large for rng_mode 1 (more than 2^32 sample slices)"); return DSRT_ERR_INVALID; }
         f.total_items *= (uint32_t)f.chunks;
-        const size_t words = out_pixels * (size_t)f.chunks * 3;
-        if (ctx->partial.n < words) { int rc = ctx->partial.alloc(words); if (rc) return rc; }
-        // not cleared: only pixels of the heavy tiles are sliced, every slice of such a pixel is written by exactly one work item,
-        // and dsrt_resolve_kernel reads nothing else (the other pixels are tone-mapped and stored by the lane that rendered them)
-        a.partial = ctx->partial.p;
+        const size_t words = out_pixels * 3;
+        if (ctx->accum_fixed.n < words) { int rc = ctx->accum_fixed.alloc(words); if (rc) return rc; }
+        HIP_TRY(hipMemsetAsync(ctx->accum_fixed.p, 0, words * sizeof(unsigned long long), stream));       // 24 bytes per pixel
+        a.accum_fixed = ctx->accum_fixed.p;
     }
     a.out_rgb8 = d_rgb8;
     a.out_f32 = d_f32;
@@ -491,6 +495,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
     a.helpers = (desc->tune[3] & 4) ? 0 : 1;
+    a.steal = (desc->tune[3] & 16) ? 0 : 1;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
@@ -519,7 +524,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         if (!(desc->tune[3] & 8) && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
             pa.frame.spp = kProbeSpp; pa.frame.chunks = 1; pa.frame.chunk_len = kProbeSpp;
-            pa.out_f32 = nullptr; pa.partial = nullptr; pa.counters = nullptr;
+            pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
             pa.tile_work = ctx->tile_work.p;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
             HIP_TRY(launch_probe(pa, blocks, stream));
@@ -533,7 +538,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
     HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
-    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a, t.mine, stream));
+    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));
     ctx->done_valid = true;
     if (stats) {

@@ -96,13 +96,15 @@ struct RenderArgs {
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
-    float*    partial;         // rng_mode 1: [output pixel][chunk][3] partial sample sums
+    unsigned long long* accum_fixed; // rng_mode 1: [output pixel][3] sample sums in units of 2^-20, added with integer atomics (exact, so the
+                               //   image does not depend on how a pixel's samples were split between work items)
     uint2*    spill;           // stack overflow area: [(entry - K) * spill_stride + global lane]
     uint32_t  spill_stride;
     int       spill_entries;
     int       min_walk_iters;  // x10: the traverse phase yields to ADVANCE once (waiting lane-slots wasted) >= this/10 * walking lanes
     int       advance_budget;  // state transitions per lane per advance phase
     int       helpers;         // 1: idle lanes trace shadow rays for busy lanes of their wave (path_machine.h)
+    int       steal;           // rng_mode 1: 1 = a lane that is out of work takes over half the remaining samples of a busy lane of its wave
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
 };
 

@@ -30,13 +30,12 @@ enum : int {
 // touches L (the next hit's terms, the end of the sample), i.e. in the reference's order; at most one delegated ray per path
 // is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
 // the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
-//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding; bit 9 kSliced;
+//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding;
 //              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`;
 //              bits 24-31: probe launch only: rays traced for the current pixel (saturating)
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
-constexpr uint32_t kSliced = 1u << 9;       // rng_mode 1: the current work item is one slice of a pixel's samples (its sum goes to `partial`)
 
 // Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
 // the DS unit retires a wave's operations in order, so no hardware instruction is needed; what IS needed is that the compiler
@@ -118,7 +117,17 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     // ray_color's return and the accumulate in render_kernel: clamp the SAMPLE to [0,1] (:935), add (:999), next sample.
     auto end_sample = [&]() {
         if (ln.aux & kAwait) { state = ST_ENDING; return; }     // L is not complete until the delegated shadow ray has answered
-        accum = accum + clamp01(L);
+        if constexpr (RNGMODE == 1) {
+            // rng_mode 1 sums a pixel's samples as integers (units of 2^-20, round to nearest): integer addition is exact and
+            // associative, so the pixel's value is the same however its samples were cut into work items or handed between lanes.
+            // The three words of `accum` hold the running sums as bit patterns; an item has at most 4095 samples (host), so no overflow.
+            const F3 s01 = clamp01(L);
+            accum.x = __uint_as_float(__float_as_uint(accum.x) + (uint32_t)(s01.x * 1048576.0f + 0.5f));
+            accum.y = __uint_as_float(__float_as_uint(accum.y) + (uint32_t)(s01.y * 1048576.0f + 0.5f));
+            accum.z = __uint_as_float(__float_as_uint(accum.z) + (uint32_t)(s01.z * 1048576.0f + 0.5f));
+        } else {
+            accum = accum + clamp01(L);
+        }
         sample++;
         restream();
         state = ST_GEN;
@@ -374,11 +383,12 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         else launch = 1;
     }
     if (state == ST_GEN && sample >= ln.sample_end) {       // sample_end == spp with rng_mode 0
-        if (RNGMODE == 1 && (ln.aux & kSliced)) {
-            // this slice of the pixel's samples is done: its partial sum goes to the slice's own slot; dsrt_resolve_kernel
-            // adds the slices in order and tone-maps
-            float* dst = args.partial + ((size_t)out_index * (size_t)P.chunks + ln.chunk) * 3;
-            dst[0] = accum.x; dst[1] = accum.y; dst[2] = accum.z;
+        if constexpr (RNGMODE == 1) {
+            // this work item's samples are done: its integer sums join the pixel's (dsrt_resolve_kernel tone-maps once all are in)
+            unsigned long long* dst = args.accum_fixed + (size_t)out_index * 3;
+            atomicAdd(dst + 0, (unsigned long long)__float_as_uint(accum.x));
+            atomicAdd(dst + 1, (unsigned long long)__float_as_uint(accum.y));
+            atomicAdd(dst + 2, (unsigned long long)__float_as_uint(accum.z));
         } else {
             // tone map + store :1003-1030
             float inv_spp = 1.0f / (float)spp;
@@ -415,7 +425,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const uint32_t tt = PROBE ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? (uint32_t)P.chunks : 1u;
-        const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt;
+        // (pixels of the light tiles are one item each, unless an item could then exceed the 4095 samples its 32-bit integer sums hold)
+        const uint32_t per_pixel_light = (RNGMODE == 1 && spp > 4095) ? per_pixel : 1u;
+        const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt * per_pixel_light;
         bool heavy = (ln.aux & 63u) < spread;
         uint32_t item;
         if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);       // (uniform address per branch:
@@ -423,11 +435,11 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             heavy = !heavy;
             if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);
         }
-        const bool sliced = RNGMODE == 1 && heavy;
+        const uint32_t pp = heavy ? per_pixel : per_pixel_light;
+        const bool sliced = RNGMODE == 1 && pp > 1u;
         ln.chunk = 0;
-        ln.aux = sliced ? (ln.aux | kSliced) : (ln.aux & ~kSliced);
         const bool none = item >= (heavy ? heavy_items : light_items);
-        if (sliced) { ln.chunk = item % per_pixel; item /= per_pixel; }
+        if (sliced) { ln.chunk = item % pp; item /= pp; }
         if (!heavy) item += n_heavy * tt;                     // position in tile_order x pixels per tile
         if (none) {
             state = ST_DONE;
@@ -456,6 +468,53 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     restream();
                 }
                 state = ST_GEN;
+            }
+        }
+    }
+    if constexpr (RNGMODE == 1) {
+        // Sample stealing.  With a Philox sub-sequence per (pixel, sample) any lane can compute any sample, and with integer sums it does
+        // not matter which lane did.  So a lane that is out of work (the queues are empty) takes over the upper half of the remaining
+        // samples of a lane of its wave that is about to start a sample and still has at least 2 * kStealMin to go: the wave then ends
+        // when its WORK ends, not when its longest item does -- which is what one rank's share of a multi-GPU frame, a few items per
+        // lane, is short of.  Matching as for the shadow-ray helpers: the r-th idle lane serves the r-th donor; the donor leaves
+        // (pixel, output index, range) in its own LDS strip, which is free between two samples.
+        constexpr int kStealMin = 4;
+        const bool idle_here = state == ST_DONE && launch == 0 && ((ln.aux >> 16) & 0x7Fu) == 0u;
+        const unsigned long long idle = args.steal ? wave_ballot(idle_here) : 0ull;
+        if (idle != 0ull) {
+            const bool donor = state == ST_GEN && ln.sample_end - sample >= 2 * kStealMin;
+            const unsigned long long donors = wave_ballot(donor);
+            if (donors != 0ull) {
+                const uint32_t pairs = min((uint32_t)__popcll(idle), (uint32_t)__popcll(donors));
+                if (donor) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+                    if (rank < pairs) {
+                        const int mid = sample + ((ln.sample_end - sample + 1) >> 1);
+                        ln.pend[13 * kPendStride + ((int)rank - (int)my_lane)] = __uint_as_float(my_lane);
+                        ln.pend[0 * kPendStride] = __uint_as_float((uint32_t)px | ((uint32_t)ky << 16));
+                        ln.pend[1 * kPendStride] = __uint_as_float(out_index);
+                        ln.pend[2 * kPendStride] = __uint_as_float((uint32_t)mid);
+                        ln.pend[3 * kPendStride] = __uint_as_float((uint32_t)ln.sample_end);
+                        ln.sample_end = mid;
+                    }
+                }
+                lane_handoff_release();
+                if (idle_here) {
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                    if (r < pairs) {
+                        lane_handoff_acquire();
+                        const uint32_t from = __float_as_uint(ln.pend[13 * kPendStride + ((int)r - (int)my_lane)]);
+                        const float* theirs = strip_of(from);
+                        const uint32_t pk = __float_as_uint(theirs[0 * kPendStride]);
+                        px = (int)(pk & 0xFFFFu); ky = (int)(pk >> 16);
+                        out_index = __float_as_uint(theirs[1 * kPendStride]);
+                        sample = (int)__float_as_uint(theirs[2 * kPendStride]);
+                        ln.sample_end = (int)__float_as_uint(theirs[3 * kPendStride]);
+                        accum = mk(0, 0, 0);                       // bit pattern 0: integer sums start at zero
+                        restream();
+                        state = ST_GEN;
+                    }
+                }
             }
         }
     }

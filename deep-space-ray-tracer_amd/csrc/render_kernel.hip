@@ -455,34 +455,22 @@ __global__ void dsrt_math_kernel(int fn, const float* __restrict__ x, float y, f
     out[i] = fn == 0 ? dsrt_sinf(x[i]) : (fn == 1 ? dsrt_cosf(x[i]) : dsrt_powf(x[i], y));
 }
 
-// rng_mode 1: add a pixel's sample slices in slice order, then the reference's tone map and 8-bit store (:1003-1030).  Only the
-// pixels of the HEAVY tiles were sliced (the first sched[0] entries of tile_order; ST_FETCH in path_machine.h): the others were
-// finished by the lane that rendered them, and their partial-sum slots were never written.
-__global__ void dsrt_resolve_kernel(const RenderArgs args) {
-    const FrameParams& P = args.frame;
-    const uint32_t tt = (uint32_t)(P.tile * P.tile);
-    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= (size_t)args.sched[0] * tt) return;
-    const uint32_t within = (uint32_t)(item % tt);
-    const uint32_t k = P.tile_order ? P.tile_order[item / tt] : (uint32_t)(item / tt);
-    const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
-    const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
-    const uint32_t in_x = within % (uint32_t)P.tile, in_y = within / (uint32_t)P.tile;
-    const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
-    if (x >= P.width || row >= P.height) return;
-    const size_t i = P.compact_output ? ((size_t)k * tt + (size_t)in_y * (size_t)P.tile + in_x) : ((size_t)row * (size_t)P.width + (size_t)x);
-    F3 acc = mk(0, 0, 0);
-    for (int c = 0; c < P.chunks; ++c) acc = acc + ld3(args.partial + (i * (size_t)P.chunks + (size_t)c) * 3);
-    const float inv_spp = 1.0f / (float)P.spp;
-    F3 col = acc * inv_spp;
+// rng_mode 1: a pixel's samples were summed as integers in units of 2^-20 (path_machine.h, end_sample); here the mean, the
+// reference's tone map and the 8-bit store (:1003-1030).  Pixels nobody sampled (culled tiles, padding) hold zero sums: black.
+__global__ void dsrt_resolve_kernel(const unsigned long long* __restrict__ sums, int spp, float inv_gamma, size_t n_pixels,
+                                    uint8_t* __restrict__ out_rgb8, float* __restrict__ out_f32) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const double unit = 1.0 / 1048576.0 / (double)spp;
+    F3 col = mk((float)((double)sums[i * 3 + 0] * unit), (float)((double)sums[i * 3 + 1] * unit), (float)((double)sums[i * 3 + 2] * unit));
     col = mk(fmaxf(col.x, 0.0f), fmaxf(col.y, 0.0f), fmaxf(col.z, 0.0f));
     col = mk(fminf(col.x, 10.0f), fminf(col.y, 10.0f), fminf(col.z, 10.0f));
-    col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
+    col = mk(dsrt_powf(col.x, inv_gamma), dsrt_powf(col.y, inv_gamma), dsrt_powf(col.z, inv_gamma));
     col = clamp01(col);
-    args.out_rgb8[i * 3 + 0] = (unsigned char)(255.99f * col.x);
-    args.out_rgb8[i * 3 + 1] = (unsigned char)(255.99f * col.y);
-    args.out_rgb8[i * 3 + 2] = (unsigned char)(255.99f * col.z);
-    if (args.out_f32) { args.out_f32[i * 3 + 0] = col.x; args.out_f32[i * 3 + 1] = col.y; args.out_f32[i * 3 + 2] = col.z; }
+    out_rgb8[i * 3 + 0] = (unsigned char)(255.99f * col.x);
+    out_rgb8[i * 3 + 1] = (unsigned char)(255.99f * col.y);
+    out_rgb8[i * 3 + 2] = (unsigned char)(255.99f * col.z);
+    if (out_f32) { out_f32[i * 3 + 0] = col.x; out_f32[i * 3 + 1] = col.y; out_f32[i * 3 + 2] = col.z; }
 }
 
 // ---- launchers (called from device_api.hip) -----------------------------------------------------------
@@ -512,10 +500,8 @@ hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_resolve(const RenderArgs& a, int local_tiles, hipStream_t stream) {
-    const size_t n = (size_t)local_tiles * (size_t)(a.frame.tile * a.frame.tile);          // upper bound; the kernel stops at sched[0] tiles
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(dsrt_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_resolve_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream, sums, spp, inv_gamma, n_pixels, out_rgb8, out_f32);
     return hipGetLastError();
 }
 

@@ -160,7 +160,9 @@ typedef struct DsrtRenderDesc {
     uint64_t seed;
     int      rng_mode;              /* 0 = reference LCG stream per pixel (parity mode, bit-exact);
                                        1 = rocRAND Philox4x32-10, one sub-sequence per (pixel, sample): samples become
-                                           independent work items (statistically equivalent image, not bit-identical to mode 0) */
+                                           independent work items (statistically equivalent image, not bit-identical to mode 0);
+                                           a pixel's samples are summed as integers in units of 2^-20, so the image is a function
+                                           of (scene, camera, seed) alone -- not of sharding, scheduling or which lane drew what */
     int      tile_size;             /* screen-tile edge in pixels, multiple of 8; 0 -> 8          */
     int      shard_rank;            /* this process renders tiles t with t % shard_count == shard_rank */
     int      shard_count;           /* 0 or 1 -> whole image                                      */
@@ -170,7 +172,8 @@ typedef struct DsrtRenderDesc {
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass flags: low two
                                        bits 1 = natural tile order and no empty-tile culling, 2 = costliest-first order but no culling;
-                                       +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order}
+                                       +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order;
+                                       +16 = rng_mode 1: idle lanes do not take over samples of busy lanes}
                                        (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 

@@ -127,9 +127,12 @@ def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(
     assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32))
     for key in ("rays", "box_fetches", "nodes_entered", "tri_tests", "hit_updates", "max_stack"):
         assert getattr(st, key) == want_cnt[key], key
-    hs_m, scene_m, _, _, _, _ = _scene(dsrt, name, "median")
-    med, _, _ = oracle.render(scene_m, W, H)
-    assert (med != want_rgb).any(axis=2).mean() < 0.03 and abs(med.astype(float).mean() - want_rgb.astype(float).mean()) < 0.6
+    if name != "textured":
+        # (`textured` is a few axis-aligned quads: which of them end up in zero-thickness leaf boxes -- boxes the reference's slab test can
+        # never hit, DESIGN.md section 8 -- depends on the tree, so there the image legitimately differs between builders)
+        hs_m, scene_m, _, _, _, _ = _scene(dsrt, name, "median")
+        med, _, _ = oracle.render(scene_m, W, H)
+        assert (med != want_rgb).any(axis=2).mean() < 0.03 and abs(med.astype(float).mean() - want_rgb.astype(float).mean()) < 0.6
     # deterministic: the same tree twice
     hs2, _, _, _, _, _ = _scene(dsrt, name, "lbvh")
     b = hs2.arrays()

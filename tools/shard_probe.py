@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--tune", type=str, default="0:0:0:0")
     ap.add_argument("--counters", action="store_true")
+    ap.add_argument("--ranks", type=str, default="", help="which ranks of the share to time (default: first, middle, last)")
     a = ap.parse_args()
     import torch
     import dsrt_amd as d
@@ -41,7 +42,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     base = None
     for n in [int(x) for x in a.shards.split(",")]:
-        ranks = sorted(set([0, n // 2, n - 1]))
+        ranks = [int(x) for x in a.ranks.split(",")] if a.ranks else sorted(set([0, n // 2, n - 1]))
         times = []
         for r in ranks:
             desc = d.make_desc(W, H, spp, 50, shard_rank=r if n > 1 else 0, shard_count=n if n > 1 else 0, rng_mode=a.rng, tile_size=a.tile, tune=tuple(int(v) for v in a.tune.split(":")))
