@@ -495,7 +495,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
     a.helpers = (desc->tune[3] & 4) ? 0 : 1;
-    a.steal = (desc->tune[3] & 16) ? 0 : 1;
+    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0);
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
@@ -523,7 +523,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
                                               // the tiles just as well (1150 +- 10 ms against 1260 without) but costs 27 ms in queue atomics.
         if (!(desc->tune[3] & 8) && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
-            pa.frame.spp = kProbeSpp; pa.frame.chunks = 1; pa.frame.chunk_len = kProbeSpp;
+            const int probe_spp = (desc->tune[3] & 64) ? 2 * kProbeSpp : kProbeSpp;                  // experiments
+            pa.frame.spp = probe_spp; pa.frame.chunks = 1; pa.frame.chunk_len = probe_spp;
             pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
             pa.tile_work = ctx->tile_work.p;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));

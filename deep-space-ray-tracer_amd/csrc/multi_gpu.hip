@@ -277,9 +277,13 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
             for (Slot& s : k.slots) { if ((rc = ensure_slot_images(s, image_bytes))) return rc; s.frame = -1; }
         }
         const auto t0 = std::chrono::steady_clock::now();
-        auto retire = [&](Slot& s) -> int {                         // the slot's previous frame is complete: hand its image over
-            HIP_TRY(hipStreamSynchronize(s.stream));
-            if (s.frame >= 0 && h_images && h_images[s.frame]) std::memcpy(h_images[s.frame], s.h_pinned, image_bytes);
+        // Before a slot is re-used its previous image is handed over -- the only reason for the host to wait on a slot.  With nobody
+        // to hand it to, stream order alone protects the slot's buffers, and not waiting keeps every slot busy while one long near
+        // frame is still rendering.
+        auto retire = [&](Slot& s, bool final_pass) -> int {
+            const bool wanted = s.frame >= 0 && h_images && h_images[s.frame];
+            if (wanted || final_pass) HIP_TRY(hipStreamSynchronize(s.stream));
+            if (wanted) std::memcpy(h_images[s.frame], s.h_pinned, image_bytes);
             s.frame = -1;
             return DSRT_OK;
         };
@@ -287,7 +291,7 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
             Rank& k = m->ranks[(size_t)(i % n)];                    // frame i -> rank i mod N, slot (i / N) mod K
             Slot& s = k.slots[(size_t)((i / n) % (int)k.slots.size())];
             HIP_TRY(hipSetDevice(k.device));
-            if ((rc = retire(s))) return rc;
+            if ((rc = retire(s, false))) return rc;
             if ((rc = dsrt_scene_set_camera_sun(s.ctx, &cams[i], sun_dirs + 3 * (size_t)i))) return rc;
             if ((rc = dsrt_render(s.ctx, &d, s.d_image, nullptr, s.stream, nullptr))) return rc;
             HIP_TRY(hipMemcpyAsync(s.h_pinned, s.d_image, image_bytes, hipMemcpyDeviceToHost, s.stream));
@@ -295,7 +299,7 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
         }
         for (Rank& k : m->ranks) {
             HIP_TRY(hipSetDevice(k.device));
-            for (Slot& s : k.slots) if ((rc = retire(s))) return rc;
+            for (Slot& s : k.slots) if ((rc = retire(s, true))) return rc;
         }
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return DSRT_OK;

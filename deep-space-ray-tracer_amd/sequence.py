@@ -50,9 +50,12 @@ class FramePipeline:
         self.n = 0
 
     def _retire(self, slot):
+        # Only a consumer of the pinned image needs the host to wait for a slot: without one, stream order alone protects the slot's
+        # buffers (its next render queues behind its last copy), and the host must NOT block here -- while it waited for one long
+        # near frame, the slots whose short far frames had finished would stand empty.
         if self.pending[slot] is not None:
-            self.streams[slot].synchronize()
             if self.on_frame is not None and self.host is not None:
+                self.streams[slot].synchronize()
                 self.on_frame(self.pending[slot], self.host[slot])
             self.pending[slot] = None
 
@@ -82,6 +85,8 @@ class FramePipeline:
     def drain(self):
         for k in range(self.K):
             self._retire((self.n + k) % self.K)                       # oldest first: frames are handed over in submission order
+        for s in self.streams:
+            s.synchronize()
 
     def close(self):
         self.drain()

@@ -173,7 +173,8 @@ typedef struct DsrtRenderDesc {
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass flags: low two
                                        bits 1 = natural tile order and no empty-tile culling, 2 = costliest-first order but no culling;
                                        +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order;
-                                       +16 = rng_mode 1: idle lanes do not take over samples of busy lanes}
+                                       +16 = rng_mode 1: idle lanes do not take over samples of busy lanes;
+                                       +32 = probe orders tiles by the sum of their pixels' cost instead of the costliest pixel}
                                        (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of render settings in ONE process on ONE box (development aid): each configuration `rng:tune3[:spp]` is rendered
+--reps times, round-robin, and the medians of the kernel times (HIP events) are printed.  Devices differ by a few per cent, so
+settings are only ever compared inside one run of this tool."""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="+", help="rng_mode:tune3 (e.g. 0:0 0:32 1:16)")
+    ap.add_argument("--tris", type=int, default=1000000)
+    ap.add_argument("--frame", type=int, default=98)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--shards", type=int, default=1)
+    ap.add_argument("--bvh", type=str, default="median")
+    a = ap.parse_args()
+    import torch
+    import dsrt_amd as d
+    from dsrt_amd import meshgen
+    obj = f"/tmp/dsrt_bench_station_v{meshgen.VERSION}_{a.tris}.obj"
+    if not os.path.exists(obj):
+        meshgen.write_obj(meshgen.build_station(a.tris), obj)
+    hs = d.HostScene().add_obj(obj)
+    hs.build_bvh(a.bvh)
+    poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))
+    fr = d.pose_to_frame(poses[a.frame])
+    W, H, spp = a.width, a.height, a.spp
+    cam = d.frame_camera(fr, 40.0, W, H, spp, 50)
+    ctx = d.Context(0)
+    ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
+    stream = torch.cuda.current_stream().cuda_stream
+    n = a.shards
+    descs = []
+    for c in a.configs:
+        rng, t3 = [int(x) for x in c.split(":")[:2]]
+        descs.append(d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(0, 0, 0, t3)))
+    lay = d.shard_layout(descs[0])
+    buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
+    times = [[] for _ in descs]
+    for dsc in descs:
+        ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True)           # warm-up
+    for _ in range(a.reps):
+        for i, dsc in enumerate(descs):
+            times[i].append(ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True).kernel_ms)
+    for c, t in zip(a.configs, times):
+        print(json.dumps({"config": c, "frame": a.frame, "shards": n, "spp": spp, "median_ms": round(statistics.median(t), 2), "all_ms": [round(x, 1) for x in t]}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
