@@ -279,7 +279,7 @@ def main():
                     help="--sequence on N > 1 GPUs: frames = poses dealt round-robin to ranks (default); tiles = every frame tile-sharded + gathered")
     ap.add_argument("--rng-mode", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=16, help="--sequence: frames in flight at once per GPU (separate streams; contexts share the scene)")
-    ap.add_argument("--bvh", choices=["median", "sah"], default="median",
+    ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -345,7 +345,10 @@ def main():
         mesh_name = f"procedural ISS-like stand-in (meshgen.py v{meshgen.VERSION}), target {args.tris} triangles"
     t0 = time.perf_counter()
     hs = d.HostScene().add_obj(obj)
+    hs.lbvh_device = local_rank
     setup["obj_parse_flatten_s"] = time.perf_counter() - t0
+    if hs.texture_failures:
+        setup["textures_not_decoded"] = hs.texture_failures[:8]     # the reference's stb_image would have decoded these: NOT the reference's picture
     t0 = time.perf_counter()
     hs.build_bvh(args.bvh)
     setup[f"bvh_build_{args.bvh}_host_s"] = time.perf_counter() - t0
@@ -458,6 +461,11 @@ def main():
     dt = timed(args.steps, args.warmup)
     my_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     headline_stats = list(last_stats)
+    rehearsal_report = None
+    if rehearsal and rank == 0:                                     # (before the rng_mode 1 steps below overwrite `image`)
+        whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
+        ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries), whole.data_ptr(), stream=stream, want_stats=True)
+        rehearsal_report = {"ranks_on_one_gpu": world, "backend": "gloo", "reassembled_image_equals_whole_frame_render": bool(torch.equal(whole, image))}
     # N > 1: the same sharded step with rng_mode 1 (a Philox sub-sequence per sample: the mode whose work units are samples, not
     # 1000-sample pixel chains, and therefore the one that can scale).  Reported beside the headline, never instead of it.
     mode1 = None
@@ -470,11 +478,6 @@ def main():
         step_desc[0] = desc
         last_stats[:] = headline_stats
     tiles_total, tiles_culled = (last_stats[0].tiles_total, last_stats[0].tiles_culled) if last_stats else (0, 0)
-    rehearsal_report = None
-    if rehearsal and rank == 0:
-        whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
-        ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries), whole.data_ptr(), stream=stream, want_stats=True)
-        rehearsal_report = {"ranks_on_one_gpu": world, "backend": "gloo", "reassembled_image_equals_whole_frame_render": bool(torch.equal(whole, image))}
 
     # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the algorithmic bytes ----
     cdesc = d.make_desc(W, H, spp, depth, shard_rank=desc.shard_rank, shard_count=desc.shard_count, collect_counters=1,
@@ -519,8 +522,21 @@ def main():
             setup["bvh_build_sah_host_s"] = time.perf_counter() - t0
             ctx.upload(hs_sah.view(cam, tuple(fr.sun_dir_model)))
             extras["runs"] += [dict(measure(args.frame, 0), bvh="sah"), dict(measure(args.frame, 1), bvh="sah")]
-            ctx.upload(scene)                                       # back to the reference tree
             del hs_sah
+            # the GPU-built linear BVH (csrc/bvh_lbvh.hip): what a per-frame rebuild costs there, and what its frames cost
+            hs_l = d.HostScene().add_obj(obj)
+            hs_l.lbvh_device = local_rank
+            try:
+                hs_l.build_bvh("lbvh")
+                hs_l.build_bvh("lbvh")                             # (the first call pays hipCUB's one-time module load)
+                setup["bvh_build_lbvh_gpu_kernels_ms"] = hs_l.lbvh_build_ms
+                setup["bvh_build_lbvh_gpu_total_ms_incl_upload_and_copy_back"] = hs_l.lbvh_total_ms
+                ctx.upload(hs_l.view(cam, tuple(fr.sun_dir_model)))
+                extras["runs"] += [dict(measure(args.frame, 0), bvh="lbvh (built on the GPU)")]
+            except d.DsrtError as e:
+                extras["lbvh_error"] = str(e)[:200]
+            del hs_l
+            ctx.upload(scene)                                       # back to the reference tree
         ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
         # the reference's own three calls, end to end (src/main.cpp:405-428): build_gpu_scene (upload in the reference layouts) ->
         # gpu_render_scene (scene fetched back, re-laid-out, uploaded, rendered, PPM written) -> free_gpu_scene; once cold, once warm
