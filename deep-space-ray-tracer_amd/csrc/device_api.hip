@@ -24,6 +24,8 @@
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
+hipError_t launch_poolcost(const RenderArgs& a, int blocks, hipStream_t stream);
+int poolcost_words();
 hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
@@ -256,6 +258,7 @@ struct DsrtContext {
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp;
     DevBuf<unsigned long long> accum_fixed;
+    DevBuf<float> pool_probe;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t done = nullptr;      // recorded behind every render: the next render on ANY stream waits for it (queue words, spill strip,
     bool done_valid = false;        // pre-pass arrays and partial sums are per context, so a context has one render in flight)
@@ -458,8 +461,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         if (f.chunk_len < 1) f.chunk_len = 1;
         if (f.chunk_len > 4095) f.chunk_len = 4095;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
-        if ((unsigned long long)f.total_items * (unsigned long long)f.chunks >= (1ull << 32)) { set_error("dsrt_render: image too large for rng_mode 1 (more than 2^32 sample slices)"); return DSRT_ERR_INVALID; }
-        f.total_items *= (uint32_t)f.chunks;
+        if ((unsigned long long)f.total_items * 64ull >= (1ull << 32)) { set_error("dsrt_render: image too large for rng_mode 1 (more than 2^32 sample slices)"); return DSRT_ERR_INVALID; }
+        f.total_items *= 64u;                                   // upper bound (the pre-pass picks 8 to 64 slices per heavy pixel): sizes the grid only
         const size_t words = out_pixels * 3;
         if (ctx->accum_fixed.n < words) { int rc = ctx->accum_fixed.alloc(words); if (rc) return rc; }
         HIP_TRY(hipMemsetAsync(ctx->accum_fixed.p, 0, words * sizeof(unsigned long long), stream));       // 24 bytes per pixel
@@ -535,9 +538,17 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     } else {
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sched, t.mine, 2, stream));           // every tile in the heavy queue, natural order
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(sched + 2), 64, 1, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(sched + 3), f.chunks, 1, stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(sched + 4), f.chunk_len, 1, stream));
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
+    if ((desc->tune[3] & 128) && desc->rng_mode == 0 && !count && !desc->checked) {       // experiment: DESIGN.md section 6, render_kernel.hip poolcost_*
+        const size_t words = (size_t)poolcost_words() * (size_t)blocks * (size_t)threads_per_block;
+        if (ctx->pool_probe.n < words) { int rc = ctx->pool_probe.alloc(words); if (rc) return rc; }
+        a.pool_probe = ctx->pool_probe.p;
+        HIP_TRY(launch_poolcost(a, blocks, stream));
+    } else
     HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));

@@ -105,6 +105,7 @@ struct RenderArgs {
     int       advance_budget;  // state transitions per lane per advance phase
     int       helpers;         // 1: idle lanes trace shadow rays for busy lanes of their wave (path_machine.h)
     int       steal;           // rng_mode 1: 1 = a lane that is out of work takes over half the remaining samples of a busy lane of its wave
+    float*    pool_probe;      // experiment (tune[3] + 128): [word][global lane] strip the path state makes a round trip through per advance pass
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
 };
 

@@ -428,7 +428,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // every work item costs one atomic on the queue word (about 13 ns each; 2 M of them are 27 ms at 1080p).
         const uint32_t tt = PROBE ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
-        const uint32_t per_pixel = RNGMODE == 1 ? (uint32_t)P.chunks : 1u;
+        const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
+        const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
         // (pixels of the light tiles are one item each, unless an item could then exceed the 4095 samples its 32-bit integer sums hold)
         const uint32_t per_pixel_light = (RNGMODE == 1 && spp > 4095) ? per_pixel : 1u;
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt * per_pixel_light;
@@ -467,8 +468,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     sample = 0;
                     ln.sample_end = spp;
                 } else {
-                    sample = sliced ? (int)ln.chunk * P.chunk_len : 0;
-                    ln.sample_end = sliced ? min(spp, sample + P.chunk_len) : spp;
+                    sample = sliced ? (int)ln.chunk * chunk_len : 0;
+                    ln.sample_end = sliced ? min(spp, sample + chunk_len) : spp;
                     restream();
                 }
                 state = ST_GEN;

@@ -38,7 +38,45 @@ constexpr int kWavesPerBlock = 4;
 #define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
+// Experiment behind DESIGN.md section 6 ("what a path pool would cost"): the price of keeping a path's state in global memory instead of
+// registers, measured in isolation.  With POOLCOST every lane that steps its state machine first LOADS 38 words (its 21 words of path
+// state plus 17 standing for the continuation and hit record, which live in LDS / registers today) from a [word][lane] strip and
+// STORES them back after the step -- the traffic, the instruction count and the cache footprint (40 MB per launch) of a pool in which a
+// path's state moves once per ray, with none of the pool's benefit.  Values make an exact round trip, so the image does not change.
+constexpr int kPoolWords = 38;
+// (plain loads and stores through a pointer the compiler cannot see through, so that they pipeline like any others -- `volatile` would make
+// hipcc wait for every access on its own -- and are neither forwarded nor removed)
+__device__ __forceinline__ float* opaque(float* p) { asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ void poolcost_store(const Lane& ln, float* base, size_t stride) {
+    float* p = opaque(base);
+    const float w[21] = {__int_as_float(ln.px), __int_as_float(ln.ky), __int_as_float(ln.sample), __int_as_float(ln.depth), __uint_as_float(ln.out_index),
+                         __uint_as_float(ln.rng), ln.accum.x, ln.accum.y, ln.accum.z, ln.thr.x, ln.thr.y, ln.thr.z, ln.L.x, ln.L.y, ln.L.z,
+                         ln.ro.x, ln.ro.y, ln.ro.z, ln.rd.x, ln.rd.y, ln.rd.z};
+#pragma unroll
+    for (int i = 0; i < 21; ++i) p[(size_t)i * stride] = w[i];
+#pragma unroll
+    for (int i = 21; i < kPoolWords; ++i) p[(size_t)i * stride] = ln.closest;
+}
+__device__ __forceinline__ void poolcost_load(Lane& ln, float* base, size_t stride) {
+    const float* p = opaque(base);
+    // straight into the registers the fields live in (no second copy of the state), the stand-in words four at a time
+    ln.px = __float_as_int(p[0 * stride]); ln.ky = __float_as_int(p[1 * stride]); ln.sample = __float_as_int(p[2 * stride]); ln.depth = __float_as_int(p[3 * stride]);
+    ln.out_index = __float_as_uint(p[4 * stride]); ln.rng = __float_as_uint(p[5 * stride]);
+    ln.accum.x = p[6 * stride]; ln.accum.y = p[7 * stride]; ln.accum.z = p[8 * stride];
+    ln.thr.x = p[9 * stride]; ln.thr.y = p[10 * stride]; ln.thr.z = p[11 * stride];
+    ln.L.x = p[12 * stride]; ln.L.y = p[13 * stride]; ln.L.z = p[14 * stride];
+    ln.ro.x = p[15 * stride]; ln.ro.y = p[16 * stride]; ln.ro.z = p[17 * stride];
+    ln.rd.x = p[18 * stride]; ln.rd.y = p[19 * stride]; ln.rd.z = p[20 * stride];
+    float sink = 0.0f;
+    for (int i = 21; i + 4 <= kPoolWords; i += 4) {
+        const float a = p[(size_t)i * stride], b = p[(size_t)(i + 1) * stride], c = p[(size_t)(i + 2) * stride], d = p[(size_t)(i + 3) * stride];
+        sink += (a + b) + (c + d);
+    }
+    sink += p[(size_t)(kPoolWords - 1) * stride];
+    asm volatile("" :: "v"(sink));
+}
+
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool POOLCOST = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -58,6 +96,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 #pragma unroll
     for (int i = 0; i < kNumCounters; ++i) c[i] = 0;
     uint32_t flags = 0;
+    float* const pool_base = POOLCOST ? args.pool_probe + glane : nullptr;
+    const size_t pool_stride = (size_t)gridDim.x * blockDim.x;
+    if (POOLCOST) poolcost_store(ln, pool_base, pool_stride);
 
     for (;;) {
         // =====================================================================================
@@ -76,7 +117,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             if (!wave_any(state < ST_TRAV_CLOSEST)) break;
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
-            if (state < ST_TRAV_CLOSEST || state == ST_DONE) advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE>(ln, args, c, flags);
+            if (state < ST_TRAV_CLOSEST || state == ST_DONE) {
+                if (POOLCOST) poolcost_load(ln, pool_base, pool_stride);
+                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE>(ln, args, c, flags);
+                if (POOLCOST) poolcost_store(ln, pool_base, pool_stride);
+            }
         }
 
         if (wave_all(state == ST_DONE)) break;
@@ -244,6 +289,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
     render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false>(args);
 }
 
+__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_poolcost_kernel(const RenderArgs args) {
+    render_body<8, false, false, true, 0, false, true>(args);
+}
+
 // The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
 // tile's entry of args.tile_work.  Its own kernel symbol, so that profiles keep it apart from the frame's launch.
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_probe_kernel(const RenderArgs args) {
@@ -369,7 +418,7 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
 
 // One block: counting sort of the shard's live tiles by cost, costliest first (65 bins; order inside a bin does not matter).
 __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile,
-                                                               uint32_t* __restrict__ sched, uint32_t items_per_pixel, uint32_t resident_lanes) {
+                                                               uint32_t* __restrict__ sched, uint32_t items_per_pixel, uint32_t resident_lanes, int spp) {
     __shared__ uint32_t bins[65], cursor[65];
     const uint32_t full = (uint32_t)(tile * tile);
     for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
@@ -383,10 +432,19 @@ __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* _
         const uint32_t n_heavy = acc - bins[64];
         // lanes per wave that start on the heavy queue: all of them once the heavy items outnumber the resident lanes, otherwise
         // just enough to deal the heavy items out over every resident wave (see ST_FETCH in path_machine.h)
-        const unsigned long long heavy_items = (unsigned long long)n_heavy * full * items_per_pixel;
+        // rng_mode 1 (items_per_pixel > 1): how many slices a heavy pixel is cut into.  8 when the heavy pixels alone fill the chip; with
+        // fewer of them (a far frame) up to 64, so that their work spreads over more WAVES -- sample stealing only evens out a wave
+        uint32_t slices = items_per_pixel, chunk_len = spp;
+        if (items_per_pixel > 1u) {
+            const unsigned long long heavy_pixels = (unsigned long long)n_heavy * full;
+            while (slices < 64u && slices * 2u <= (uint32_t)spp && heavy_pixels * slices * 2ull <= resident_lanes) slices *= 2u;
+            chunk_len = ((uint32_t)spp + slices - 1u) / slices;
+            slices = ((uint32_t)spp + chunk_len - 1u) / chunk_len;
+        }
+        const unsigned long long heavy_items = (unsigned long long)n_heavy * full * slices;
         uint32_t spread = 64;
         if (heavy_items < resident_lanes) spread = (uint32_t)((heavy_items * 64ull + resident_lanes - 1) / resident_lanes);
-        sched[0] = n_heavy; sched[1] = acc; sched[2] = spread < 1 ? 1u : spread;
+        sched[0] = n_heavy; sched[1] = acc; sched[2] = spread < 1 ? 1u : spread; sched[3] = slices; sched[4] = chunk_len;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < n; t += blockDim.x)
@@ -431,7 +489,7 @@ hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_
     hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost, cull ? 1 : 0);
-    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, sched, items_per_pixel, resident_lanes);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, sched, items_per_pixel, resident_lanes, P.spp);
     return hipGetLastError();
 }
 
@@ -487,6 +545,12 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
     }
     return hipGetLastError();
 }
+
+hipError_t launch_poolcost(const RenderArgs& a, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_poolcost_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+    return hipGetLastError();
+}
+int poolcost_words() { return kPoolWords; }
 
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(dsrt_probe_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
