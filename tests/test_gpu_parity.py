@@ -369,7 +369,7 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
     scene = hs.view(cam, SUN)
     want_rgb, want_f32, _ = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    for flags in (0, 1, 2, 4, 8, 12, 5, 14):
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 40, 128):        # (128: the path-state round trip of the pool-cost experiment)
         rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
     # rng_mode 1 sums samples as integers, so neither the scheduling switches nor sample stealing (+16 switches it off) may move a bit
