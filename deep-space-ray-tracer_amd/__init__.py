@@ -157,6 +157,15 @@ def frame_camera(frame, vfov, width, height, spp, max_depth):
     return camera_look_at(tuple(frame.cam_in_model), (0.0, 0.0, 0.0), vfov, width, height, spp, max_depth)
 
 
+def decode_image_file(path, flip_vertically=False):
+    """The builder's texture decoder on one file -> H x W x 3 uint8 (dsrt_decode_image_file)."""
+    w, h = C.c_int(), C.c_int()
+    _check(lib.dsrt_decode_image_file(str(path).encode(), int(bool(flip_vertically)), C.byref(w), C.byref(h), None, 0), "dsrt_decode_image_file")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    _check(lib.dsrt_decode_image_file(str(path).encode(), int(bool(flip_vertically)), C.byref(w), C.byref(h), out.ctypes.data, out.size), "dsrt_decode_image_file")
+    return out
+
+
 def write_ppm(path, rgb, width, height):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     _check(lib.dsrt_write_ppm(str(path).encode(), rgb.ctypes.data, int(width), int(height)), "dsrt_write_ppm")

@@ -104,7 +104,7 @@ EXPORTS = [
     "dsrt_last_error", "dsrt_abi_version",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
-    "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_write_ppm", "dsrt_write_png",
+    "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
     "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
     "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_render", "dsrt_deinterleave_tiles", "dsrt_render_to_host",
@@ -143,6 +143,7 @@ def load():
     sig("dsrt_read_pose_file", C.c_int, [C.c_char_p, P(DsrtPose), C.c_int, P(C.c_int)])
     sig("dsrt_pose_to_frame", C.c_int, [P(DsrtPose), P(DsrtFrame)])
     sig("dsrt_camera_look_at", C.c_int, [P(GPUCamera), P(C.c_float), P(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, C.c_int])
+    sig("dsrt_decode_image_file", C.c_int, [C.c_char_p, C.c_int, P(C.c_int), P(C.c_int), vp, C.c_size_t])
     sig("dsrt_write_ppm", C.c_int, [C.c_char_p, vp, C.c_int, C.c_int])
     sig("dsrt_write_png", C.c_int, [C.c_char_p, vp, C.c_int, C.c_int])
     sig("dsrt_device_count", C.c_int, [])

@@ -29,6 +29,7 @@ struct RgbImage {
     std::vector<uint8_t> rgb;
 };
 bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img);
+bool decode_jpeg(const std::vector<uint8_t>& file_bytes, RgbImage& img);      // jpeg_decode.cpp
 
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);

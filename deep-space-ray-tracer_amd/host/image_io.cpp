@@ -1,11 +1,12 @@
-// image_io.cpp -- texture decode (PNM, PNG) to 8-bit RGB, and the P6 writer.
+// image_io.cpp -- texture decode (PNM, PNG here; JPEG in jpeg_decode.cpp) to 8-bit RGB, and the P6 / PNG writers.
 //
 // The reference decodes textures with its vendored stb_image forced to 3 channels
 // (src/gpu_scene_builder.cpp:215) and writes frames as binary PPM (src/gpu_render.cu:1099-1107).
 // This file is an independent implementation of the two container formats we can support without
-// third-party code: binary/ASCII PNM and non-interlaced PNG (inflate through the system zlib).  Any other
-// format -- JPEG above all -- is reported as a load failure, for which the reference's own behaviour is a
-// 1x1 white texture plus a warning (src/gpu_scene_builder.cpp:216-221); the builder does the same.
+// third-party code: binary/ASCII PNM, non-interlaced PNG (inflate through the system zlib) and baseline /
+// progressive JPEG (jpeg_decode.cpp).  Any other format (BMP, TGA, GIF, PSD, interlaced PNG, CMYK JPEG) is a load
+// failure, for which the reference's own behaviour is a 1x1 white texture plus a warning
+// (src/gpu_scene_builder.cpp:216-221); the builder does the same and reports it (dsrt_host_scene_texture_failures).
 // Channel handling matches stb's req_comp = 3: gray is replicated, alpha is dropped, 16-bit keeps the
 // high byte, palette entries are expanded.
 #include "host_internal.hpp"
@@ -183,7 +184,7 @@ bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
 bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img) {
     std::vector<uint8_t> f;
     if (!read_file(path, f)) return false;
-    if (!decode_png(f, img) && !decode_pnm(f, img)) return false;
+    if (!decode_png(f, img) && !decode_pnm(f, img) && !decode_jpeg(f, img)) return false;
     if (flip_vertically) {
         const size_t row = (size_t)img.width * 3;
         std::vector<uint8_t> tmp(row);
@@ -197,6 +198,20 @@ bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img) {
 }
 
 }  // namespace dsrt
+
+extern "C" int dsrt_decode_image_file(const char* path, int flip_vertically, int* width, int* height, uint8_t* rgb, size_t cap) {
+    if (!path || !width || !height) { dsrt::set_error("dsrt_decode_image_file: null argument"); return DSRT_ERR_INVALID; }
+    return dsrt::guarded("dsrt_decode_image_file", [&]() -> int {
+        dsrt::RgbImage img;
+        if (!dsrt::load_rgb8(path, flip_vertically != 0, img)) { dsrt::set_error(std::string("cannot decode ") + path); return DSRT_ERR_IO; }
+        *width = img.width; *height = img.height;
+        if (rgb) {
+            if (cap < img.rgb.size()) { dsrt::set_error("dsrt_decode_image_file: buffer too small"); return DSRT_ERR_INVALID; }
+            std::memcpy(rgb, img.rgb.data(), img.rgb.size());
+        }
+        return DSRT_OK;
+    });
+}
 
 extern "C" int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, int height) {
     if (!path || !rgb || width <= 0 || height <= 0) { dsrt::set_error("dsrt_write_ppm: bad argument"); return DSRT_ERR_INVALID; }

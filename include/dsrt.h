@@ -82,8 +82,8 @@ int dsrt_host_scene_build_bvh_gpu(DsrtHostScene* hs, int device, float* build_ms
 int dsrt_host_scene_view(const DsrtHostScene* hs, GPUScene* out);
 
 /* Textures that could not be decoded while objects were added.  Like the reference (stbi_load failure, src/gpu_scene_builder.cpp:216-221)
- * the builder goes on with a 1x1 white texel for such a map and prints a warning -- but the reference's stb_image decodes JPEG, BMP,
- * TGA, GIF, PSD, HDR, PIC and interlaced PNG, while this library decodes PNM and non-interlaced PNG only.  A scene for which this returns
+ * the builder goes on with a 1x1 white texel for such a map and prints a warning -- but the reference's stb_image also decodes BMP,
+ * TGA, GIF, PSD, HDR, PIC, interlaced PNG and CMYK JPEG, while this library decodes PNM, non-interlaced PNG and 1- or 3-component JPEG only.  A scene for which this returns
  * non-zero therefore does NOT render like the reference would; hosts that care should refuse it (dsrt_render --strict-textures does,
  * bench.py labels the run).  Returns the number of failed maps; if `names` is given, their paths, newline-separated, as far as `cap` allows. */
 int dsrt_host_scene_texture_failures(const DsrtHostScene* hs, char* names, size_t cap);
@@ -120,6 +120,11 @@ int dsrt_pose_to_frame(const DsrtPose* pose, DsrtFrame* out);
 /* point_camera_at + camera::initialize + toGPUCamera: vup (0,1,0), aperture 0, focus = |from - at|. */
 int dsrt_camera_look_at(GPUCamera* out, const float from[3], const float at[3], float vfov_deg, int width, int height,
                         int spp, int max_depth);
+
+/* Decode a texture file exactly as the scene builder does (PNM, non-interlaced PNG, baseline / progressive JPEG; forced to 3 channels like the
+ * reference's stbi_load(..., 3), src/gpu_scene_builder.cpp:215; `flip_vertically` as stbi_set_flip_vertically_on_load).  Pass rgb = NULL to ask
+ * for the size only.  DSRT_ERR_IO if the file cannot be read or is in a format this library does not decode. */
+int dsrt_decode_image_file(const char* path, int flip_vertically, int* width, int* height, uint8_t* rgb, size_t cap);
 
 /* P6 writer, as the tail of gpu_render_scene (src/gpu_render.cu:1099-1107). */
 int dsrt_write_ppm(const char* path, const uint8_t* rgb, int width, int height);

@@ -13,14 +13,20 @@
  * Pinning status (read before trusting it):
  *   - The reference has no tests, golden images or known-answer vectors, and its
  *     render kernel is a CUDA translation unit that cannot be built in this image (no nvcc, no
- *     libcudart; we do not write stand-ins).  The sampling loop restated here is therefore
- *     **parity unpinned** against an execution of the reference: it is a line-by-line
- *     restatement checked by review, by the LCG / pose known answers SURVEY.md section 8 records, and
- *     by cross-checks against the reference's own CPU classes (sphere::hit, triangle::hit,
- *     aabb::hit) where those compute the same quantity.
- *   - Everything that FEEDS the loop (pose -> camera, OBJ/MTL -> triangles/materials, flattening,
- *     median-split BVH) is pinned against the reference's real host code compiled from
- *     /root/reference by oracle/Makefile into oracle/_ref/ (goldens in tests/golden/).
+ *     libcudart; we do not write stand-ins).  What CAN be executed is pinned:
+ *       * everything that FEEDS the loop (pose -> camera, OBJ/MTL -> triangles/materials, flattening,
+ *         median-split BVH) against the reference's real host code compiled from /root/reference by
+ *         oracle/Makefile into oracle/_ref/ (goldens in tests/golden/ref_*);
+ *       * bbox_hit / hit_sphere / Moller-Trumbore against the reference's CPU classes aabb::hit (exact),
+ *         sphere::hit, triangle::hit (to rounding), tests/golden/ref_hitkat.json;
+ *       * rand01, the rejection loop of random_in_unit_sphere, the local cosine direction and the
+ *         camera-ray set-up against the reference's own host-compilable DEVICE helpers, executed
+ *         (inc/rtweekend.h:126-202, inc/camera.h:35-61; tests/golden/ref_devkat.json): bit for bit where
+ *         the arithmetic is float or exact, to 4e-7 where the helper computes in double.
+ *   - What remains **parity unpinned** against an execution of the reference: ray_color's control flow
+ *     (:715-936: Russian roulette, sun NEE, the mixture branch, the per-sample clamp), scene_hit's
+ *     combination of BVH and spheres (:509-551) and the traversal ORDER of bvh_hit_closest (:387-473,
+ *     which decides equal-distance ties).  These are a line-by-line restatement checked by review.
  *   - cosf/sinf/powf come from include/dsrt_detmath.h (shared with the HIP kernel), not from any
  *     libm: see that header.  Build with -DDSRT_ORACLE_LIBM to use the host libm instead (for the
  *     statistical comparison only).

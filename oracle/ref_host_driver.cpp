@@ -281,10 +281,24 @@ static int cmd_devkat(int n) {
     return 0;
 }
 
+// The reference's texture decoder on one file: stbi_load(path, &w, &h, &n, 3), the call of src/gpu_scene_builder.cpp:215
+// (the flip flag of inc/texture.h:133 is a separate, global switch; `flip` sets it like image_texture::load does).
+static int cmd_decode(const char* path, int flip) {
+    stbi_set_flip_vertically_on_load(flip);
+    int w = 0, h = 0, n = 0;
+    unsigned char* img = stbi_load(path, &w, &h, &n, 3);
+    if (!img) { std::printf("{\"ok\": 0}\n"); return 0; }
+    std::printf("{\"ok\": 1, \"w\": %d, \"h\": %d, \"file_channels\": %d, \"rgb\": \"", w, h, n);
+    hex_bytes(img, (size_t)w * h * 3);
+    std::printf("\"}\n");
+    stbi_image_free(img);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: ref_host abi | scene <world.txt> <prefix> | camera fx fy fz ax ay az vfov W H spp depth |"
-                             " poses <pose.txt> W H spp depth vfov | hitkat <n> | devkat <n>\n");
+                             " poses <pose.txt> W H spp depth vfov | hitkat <n> | devkat <n> | decode <image> [flip]\n");
         return 2;
     }
     std::string c = argv[1];
@@ -294,5 +308,6 @@ int main(int argc, char** argv) {
     if (c == "poses") return cmd_poses(argc, argv);
     if (c == "hitkat" && argc >= 3) return cmd_hitkat(std::atoi(argv[2]));
     if (c == "devkat" && argc >= 3) return cmd_devkat(std::atoi(argv[2]));
+    if (c == "decode" && argc >= 3) return cmd_decode(argv[2], argc >= 4 ? std::atoi(argv[3]) : 0);
     return 2;
 }
