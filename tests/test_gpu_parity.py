@@ -479,8 +479,9 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSRT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29531",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--tris", "20000", "--width", "322", "--height", "190",
+    # `python bench.py --gpus 2` from a plain interpreter -- the way the driver calls it for N = 1 -- must start the two-rank job itself
+    # (one process per rank through torch.distributed.run) and hand back its exit code and its JSON line, never run one GPU silently
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--tris", "20000", "--width", "322", "--height", "190",
            "--spp", "16", "--no-cpu"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -489,6 +490,7 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "Msamples/s"
     assert out["rehearsal"]["reassembled_image_equals_whole_frame_render"] is True
     assert out["value"] > 0 and out["roofline"]["achieved_algorithmic_GBps"] > 0 and out["roofline"]["kernel_ms"] > 0
+    assert out["rng_mode_1_same_sharding"]["value"] > 0              # both generators are reported for the sharded step
 
 
 def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
