@@ -524,7 +524,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         // long chain; tune[3] bit 3 (value 8) switches it off.
         constexpr int kProbeSpp = 4;          // x one pixel in four of the heavy tiles: 6 ms at 1080p.  Every pixel at 1, 2, 4 or 8 samples orders
                                               // the tiles just as well (1150 +- 10 ms against 1260 without) but costs 27 ms in queue atomics.
-        if (!(desc->tune[3] & 8) && f.spp >= 64 * kProbeSpp) {
+        // Only with the reference's stream: in rng_mode 1 a pixel is cut into slices and lanes share samples, so there is no long chain to start
+        // early, and the coverage order alone is better (interleaved medians, near frame: 1046 -> 1037 ms, one of 8 shares 176 -> 167 ms).
+        if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
             const int probe_spp = (desc->tune[3] & 64) ? 2 * kProbeSpp : kProbeSpp;                  // experiments
             pa.frame.spp = probe_spp; pa.frame.chunks = 1; pa.frame.chunk_len = probe_spp;
