@@ -1,7 +1,7 @@
 """ctypes view of the C ABI in include/dsrt.h and the PODs of include/dsrt_scene_abi.h.
 
 Nothing here computes anything: it declares the structs field for field (their offsets are asserted against the
-reference's in tests/test_abi_layout.py) and binds the entry points of libdsrt_hip.so.  The library is required:
+reference's in tests/test_host_golden.py::test_abi_matches_reference_layout) and binds the entry points of libdsrt_hip.so.  The library is required:
 importing this module without it raises -- there is no Python or CPU fallback for the render path.
 """
 import ctypes as C

@@ -9,7 +9,7 @@
  * (from <cuda_runtime.h>) and `vec3` (class with float e[3], inc/vec3.h:14-22); both are
  * 12 bytes / 4-byte aligned, which is what DsrtF3 is.  Offsets are pinned by the static
  * assertions at the bottom (values: SURVEY.md section 8(b), re-measured in
- * tests/test_abi_layout.py against the reference headers compiled in oracle/_ref).
+ * tests/test_host_golden.py::test_abi_matches_reference_layout against the reference headers compiled in oracle/_ref).
  *
  * Plain C: usable from C, C++, HIP and (through ctypes) Python.
  */

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("configs", nargs="+", help="rng_mode:tune3 (e.g. 0:0 0:32 1:16)")
+    ap.add_argument("configs", nargs="+", help="rng_mode:tune3[:min_walk:adv_budget:leaf_ratio] (e.g. 0:0 0:32 1:16 0:0:96:12:16)")
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--frame", type=int, default=98)
     ap.add_argument("--width", type=int, default=1920)
@@ -42,8 +42,10 @@ def main():
     n = a.shards
     descs = []
     for c in a.configs:
-        rng, t3 = [int(x) for x in c.split(":")[:2]]
-        descs.append(d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(0, 0, 0, t3)))
+        parts = [int(x) for x in c.split(":")]
+        rng, t3 = parts[0], parts[1]
+        t0, t1, t2 = (parts[2:5] + [0, 0, 0])[:3]                     # optional: min_walk_iters : advance_budget : leaf_ratio4
+        descs.append(d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, t3)))
     lay = d.shard_layout(descs[0])
     buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
     times = [[] for _ in descs]
