@@ -34,7 +34,7 @@ hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipSt
 int kernel_waves_per_block();
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
                              uint32_t resident_lanes, bool cull, hipStream_t stream);
-hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream);
+hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, int small_mode, hipStream_t stream);
 hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
 }  // namespace dsrt
 
@@ -256,7 +256,7 @@ struct DsrtContext {
     int sun_enabled = 0;
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
-    DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp;
+    DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp, probe_queue;
     DevBuf<unsigned long long> accum_fixed;
     DevBuf<float> pool_probe;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -522,8 +522,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         // Probe: the render kernel itself at kProbeSpp samples per pixel (reference stream, output discarded: the frame overwrites
         // it) measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.5 % only when a pixel is a
         // long chain; tune[3] bit 3 (value 8) switches it off.
-        constexpr int kProbeSpp = 4;          // x one pixel in four of the heavy tiles: 6 ms at 1080p.  Every pixel at 1, 2, 4 or 8 samples orders
-                                              // the tiles just as well (1150 +- 10 ms against 1260 without) but costs 27 ms in queue atomics.
+        constexpr int kProbeSpp = 4;          // x every pixel of the heavy tiles: 7 ms at 1080p, near frame.  (1, 2, 4 or 8 samples order the tiles equally well.)
+        // Its work items are tiny, so the probe has 64 queue words of its own (path_machine.h, ST_FETCH): on the frame's single queue word
+        // the same launch took 27 ms.  tune[3] + (1 << 22) probes one pixel in four (round 2's first version: 4.4 ms, near frame 3 % slower).
         // Only with the reference's stream: in rng_mode 1 a pixel is cut into slices and lanes share samples, so there is no long chain to start
         // early, and the coverage order alone is better (interleaved medians, near frame: 1046 -> 1037 ms, one of 8 shares 176 -> 167 ms).
         if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 64 * kProbeSpp) {
@@ -532,9 +533,13 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
             pa.frame.spp = probe_spp; pa.frame.chunks = 1; pa.frame.chunk_len = probe_spp;
             pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
             pa.tile_work = ctx->tile_work.p;
+            if (ctx->probe_queue.n < 1024) { int rc = ctx->probe_queue.alloc(1024); if (rc) return rc; }
+            HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
+            pa.probe_queue = ctx->probe_queue.p;
+            pa.probe_all = (desc->tune[3] & (1 << 22)) ? 0 : 1;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
             HIP_TRY(launch_probe(pa, blocks, stream));
-            HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, stream));
+            HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, (desc->tune[3] >> 20) & 3, stream));       // experiments: 1 = keep the coverage order, 2 = plain sorted order, when all start at once
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
         }
     } else {

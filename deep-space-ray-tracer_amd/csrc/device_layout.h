@@ -93,6 +93,8 @@ struct RenderArgs {
                                //   [0] n_heavy  tiles that see geometry (the first n_heavy entries of tile_order)
                                //   [1] n_live   tiles in tile_order: the shard's tiles minus those proven empty
                                //   [2] spread   lanes per wave (1..64) that serve the heavy queue first; the others start on the light one
+    uint32_t* probe_queue;     // probe launch only: 64 queue words, 64 bytes apart (path_machine.h, ST_FETCH)
+    int       probe_all;       // probe launch only: 1 = every pixel of the heavy tiles, 0 = one in four
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word

@@ -424,21 +424,30 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // items are dealt out `spread` per wave over ALL resident waves instead of filling the first waves with 64 serial chains
         // each and leaving the rest of the chip with nothing to interleave: a wave's run time grows with the number of long
         // chains it holds, because lanes in different phases take turns.  Only the assignment of pixels to lanes changes.
-        // The probe visits one pixel in four (even column, even row) of the heavy tiles only: a tile's cost is wanted, and
-        // every work item costs one atomic on the queue word (about 13 ns each; 2 M of them are 27 ms at 1080p).
-        const uint32_t tt = PROBE ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
+        // The probe visits the heavy tiles only, every pixel (a tile's place is decided by its costliest pixel, so a sample of its
+        // pixels misses it: all against one in four, near frame 1157 -> 1126 ms, spread 1141-1162 -> 1114-1131).
+        const bool probe_all = PROBE && args.probe_all;          // 0 = one pixel in four (even column, even row): an experiment switch
+        const uint32_t tt = (PROBE && !probe_all) ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
         const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
         // (pixels of the light tiles are one item each, unless an item could then exceed the 4095 samples its 32-bit integer sums hold)
         const uint32_t per_pixel_light = (RNGMODE == 1 && spp > 4095) ? per_pixel : 1u;
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt * per_pixel_light;
-        bool heavy = (ln.aux & 63u) < spread;
+        bool heavy = PROBE || (ln.aux & 63u) < spread;
         uint32_t item;
-        if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);       // (uniform address per branch:
-        if (item >= (heavy ? heavy_items : light_items)) {                                              //  one atomic per wave)
-            heavy = !heavy;
-            if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);
+        if constexpr (PROBE) {
+            // The probe's work items are tiny (a few samples), so its queue word would be the bottleneck: one returning atomic on one address
+            // costs about 13 ns, and half a million of them are the probe's whole run time.  64 queue words on lines of their own, picked by
+            // wave number, each handing out the items congruent to its number modulo 64: the atomics of different waves no longer queue up.
+            const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63u;
+            item = shard + 64u * atomicAdd(args.probe_queue + shard * 16u, 1u);
+        } else {
+            if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);   // (uniform address per branch:
+            if (item >= (heavy ? heavy_items : light_items)) {                                          //  one atomic per wave)
+                heavy = !heavy;
+                if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);
+            }
         }
         const uint32_t pp = heavy ? per_pixel : per_pixel_light;
         const bool sliced = RNGMODE == 1 && pp > 1u;
@@ -454,8 +463,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
             const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
             const uint32_t per_row = (uint32_t)P.tile >> 3;
-            const uint32_t sub = PROBE ? within >> 4 : within >> 6;                        // which 8x8 block of the tile
-            const uint32_t lx = PROBE ? (within & 3u) << 1 : within & 7u, ly = PROBE ? ((within >> 2) & 3u) << 1 : (within >> 3) & 7u;
+            const bool quarter = PROBE && !probe_all;                                      // even column, even row only
+            const uint32_t sub = quarter ? within >> 4 : within >> 6;                      // which 8x8 block of the tile
+            const uint32_t lx = quarter ? (within & 3u) << 1 : within & 7u, ly = quarter ? ((within >> 2) & 3u) << 1 : (within >> 3) & 7u;
             const uint32_t in_x = (sub % per_row) * 8u + lx, in_y = (sub / per_row) * 8u + ly;
             const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
             if (x < W && row < H) {

@@ -456,9 +456,17 @@ __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* _
 // entries of `order` -- are re-sorted by it, most work first, so the pixels with the longest serial sample chains start at
 // once instead of wherever their tile's coverage count put them.  Scheduling only.
 __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, uint32_t* __restrict__ tmp,
-                                                                 const uint32_t* __restrict__ sched) {
+                                                                 const uint32_t* __restrict__ sched, int small_mode) {
     __shared__ uint32_t bins[256], cursor[256], wmax;
     const uint32_t n = sched[0];
+    // Fewer heavy pixels than resident lanes (a mid-distance frame; one rank's share): every heavy pixel starts in the first instant
+    // whatever the order, and the order only decides which waves -- fetching at the same moment, so mostly neighbours on a CU --
+    // hold the long chains.  Sorted, the costliest tiles sit side by side; dealt costliest, cheapest, second costliest, ... a long
+    // chain's neighbours finish early and leave it the SIMD.  Interleaved medians at 1080p x 1000 (sorted / dealt / coverage order /
+    // no probe): frame 75 387 / 361 / 374 / 374 ms, frame 85 400 / 388 / 368 / 373, frame 90 505 / 500 / 512 / 479, one of 8 shares of
+    // the near frame 564 / 563 / 625 / 610 (profiles/r02/ab_small_regime_order.jsonl); one setting spreads +-5 % on such frames.
+    const bool all_start_at_once = sched[2] < 64u;
+    if (all_start_at_once && small_mode == 1) return;       // experiment: keep the coverage order
     for (int b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
     if (threadIdx.x == 0) wmax = 1u;
     __syncthreads();
@@ -476,10 +484,16 @@ __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t*
         const uint32_t t = tmp[i];
         order[atomicAdd(&cursor[255u - (uint32_t)((unsigned long long)work[t] * 255ull / top)], 1u)] = t;
     }
+    if (all_start_at_once && small_mode == 0) {             // costliest, cheapest, second costliest, second cheapest, ...
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tmp[i] = order[i];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[i] = (i & 1u) ? tmp[n - 1u - (i >> 1)] : tmp[i >> 1];
+    }
 }
 
-hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream) {
-    hipLaunchKernelGGL(dsrt_tile_reorder_kernel, dim3(1), dim3(1024), 0, stream, work, order, tmp, sched);
+hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, int small_mode, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_tile_reorder_kernel, dim3(1), dim3(1024), 0, stream, work, order, tmp, sched, small_mode);
     return hipGetLastError();
 }
 

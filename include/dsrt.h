@@ -179,7 +179,11 @@ typedef struct DsrtRenderDesc {
                                        bits 1 = natural tile order and no empty-tile culling, 2 = costliest-first order but no culling;
                                        +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order;
                                        +16 = rng_mode 1: idle lanes do not take over samples of busy lanes;
-                                       +32 = probe orders tiles by the sum of their pixels' cost instead of the costliest pixel}
+                                       +32 = probe orders tiles by the sum of their pixels' cost instead of the costliest pixel;
+                                       +64 = 8 probe samples instead of 4; +128 = the state-move cost experiment;
+                                       bits 8-19 = rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass);
+                                       bits 20-21 = probe order when every heavy pixel starts at once: 0 = dealt costliest / cheapest
+                                       alternately, 1 = coverage order kept, 2 = plain costliest first; +(1 << 22) = probe one pixel in four}
                                        (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 

@@ -361,15 +361,16 @@ def test_empty_tile_culling_is_exact(dsrt, gpu_ctx, oracle):
 
 
 def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
-    """Probe-refined tile order (active from 128 spp), shadow-ray helpers, culling, natural order: every combination gives the
-    oracle's bytes.  128 spp on a small image: most lanes are idle, so nearly every shadow ray is traced by a helper lane."""
+    """Probe-refined tile order (active from 256 spp), shadow-ray helpers, culling, natural order: every combination gives the
+    oracle's bytes.  256 spp on a small image: most lanes are idle, so nearly every shadow ray is traced by a helper lane."""
     hs, scene, W, H, _, depth = _scene(dsrt, "station_near")
-    W, H, spp = 96, 54, 128
+    W, H, spp = 96, 54, 256
     cam = dsrt.camera_look_at((12.0, 9.0, 38.0), (0.0, 0.0, 0.0), 40.0, W, H, spp, depth)
     scene = hs.view(cam, SUN)
     want_rgb, want_f32, _ = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 40, 128):        # (128: the path-state round trip of the pool-cost experiment, DESIGN.md section 6)
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 40, 64, 128, 1 << 20, 2 << 20, 1 << 22, (1 << 22) + 32 + (2 << 20)):
+        # (128: the path-state round trip of the pool-cost experiment, DESIGN.md section 6; 1 << 20 and up: probe variants, include/dsrt.h)
         rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
     # rng_mode 1 sums samples as integers, so neither the scheduling switches nor sample stealing (+16 switches it off) may move a bit

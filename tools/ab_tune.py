@@ -48,14 +48,20 @@ def main():
         descs.append(d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, t3)))
     lay = d.shard_layout(descs[0])
     buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
+    import time
     times = [[] for _ in descs]
+    walls = [[] for _ in descs]
     for dsc in descs:
         ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True)           # warm-up
     for _ in range(a.reps):
         for i, dsc in enumerate(descs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             times[i].append(ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True).kernel_ms)
-    for c, t in zip(a.configs, times):
-        print(json.dumps({"config": c, "frame": a.frame, "shards": n, "spp": spp, "median_ms": round(statistics.median(t), 2), "all_ms": [round(x, 1) for x in t]}), flush=True)
+            walls[i].append((time.perf_counter() - t0) * 1e3)                      # the whole call: pre-pass, probe, render, (resolve)
+    for c, t, w in zip(a.configs, times, walls):
+        print(json.dumps({"config": c, "frame": a.frame, "shards": n, "spp": spp, "median_ms": round(statistics.median(t), 2), "median_wall_ms": round(statistics.median(w), 2),
+                          "all_ms": [round(x, 1) for x in t]}), flush=True)
 
 
 if __name__ == "__main__":
