@@ -461,6 +461,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         if (f.chunk_len < 1) f.chunk_len = 1;
         if (f.chunk_len > 4095) f.chunk_len = 4095;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
+        if (desc->width > 65535 || desc->height > 65535) { set_error("dsrt_render: rng_mode 1 hands samples between lanes with 16-bit pixel coordinates (width, height <= 65535)"); return DSRT_ERR_INVALID; }
         if ((unsigned long long)f.total_items * 64ull >= (1ull << 32)) { set_error("dsrt_render: image too large for rng_mode 1 (more than 2^32 sample slices)"); return DSRT_ERR_INVALID; }
         f.total_items *= 64u;                                   // upper bound (the pre-pass picks 8 to 64 slices per heavy pixel): sizes the grid only
         const size_t words = out_pixels * 3;
@@ -498,7 +499,13 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
     a.helpers = (desc->tune[3] & 4) ? 0 : 1;
-    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0);
+    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0) | (((uint32_t)desc->tune[3] & 0x80000000u) ? 4 : 0);      // (bit 31: experiment, light pixels unsliced)
+    // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
+    // Interleaved medians, 1080p x 1000: near frame 1117 -> 1108 ms, frame 95 801 -> 785 ms.  Finer grades (the top quarter and sixteenth of
+    // the order above the rest) move nothing consistently: near frame 1103, frame 95 801; one of 8 shares 543 ms with every setting -- a
+    // long chain is bound by its own latency, not by its neighbours (profiles/r02/ab_issue_priority.jsonl).  Field 7 = off, 2-6 = experiments.
+    { const int f = (desc->tune[3] >> 23) & 7; a.hot_shift = f == 0 ? 1 : (f == 7 ? 0 : f); }
+    a.hot_graded = (desc->tune[3] >> 26) & 1;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
@@ -579,6 +586,13 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         stats->max_stack = cnt[C_MAX_STACK];
         stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
+        stats->wave_ticks = cnt[C_WAVE_TICKS];
+        {   // time marks relative to the first wave's start, in ms (0 when the mark was never passed)
+            const double t0 = (double)~cnt[C_T_FIRST];
+            stats->heavy_queue_empty_ms = cnt[C_T_HEAVY_EMPTY] ? (float)(((double)~cnt[C_T_HEAVY_EMPTY] - t0) * 1e-5) : 0.0f;
+            stats->light_queue_empty_ms = cnt[C_T_LIGHT_EMPTY] ? (float)(((double)~cnt[C_T_LIGHT_EMPTY] - t0) * 1e-5) : 0.0f;
+            stats->last_wave_exit_ms = cnt[C_T_LAST] ? (float)(((double)cnt[C_T_LAST] - t0) * 1e-5) : 0.0f;
+        }
         stats->visits_depth_lt6 = cnt[C_VISITS_LT6]; stats->visits_depth_lt9 = cnt[C_VISITS_LT9]; stats->visits_depth_lt12 = cnt[C_VISITS_LT12];
         uint32_t live = 0;
         HIP_TRY(hipMemcpy(&live, sched + 1, sizeof live, hipMemcpyDeviceToHost));

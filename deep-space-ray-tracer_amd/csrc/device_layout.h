@@ -94,6 +94,8 @@ struct RenderArgs {
                                //   [1] n_live   tiles in tile_order: the shard's tiles minus those proven empty
                                //   [2] spread   lanes per wave (1..64) that serve the heavy queue first; the others start on the light one
     uint32_t* probe_queue;     // probe launch only: 64 queue words, 64 bytes apart (path_machine.h, ST_FETCH)
+    int       hot_shift;       // rng_mode 0: 0 = off; s > 0: pixels of the first n_heavy >> (s - 1) tiles of the order raise their wave's issue priority
+    int       hot_graded;      //   1 = three levels (that share, a quarter and a sixteenth of it), 0 = one level
     int       probe_all;       // probe launch only: 1 = every pixel of the heavy tiles, 0 = one in four
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
@@ -115,7 +117,9 @@ struct RenderArgs {
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
                C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
-               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, kNumCounters };
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_WAVE_TICKS,
+               C_T_FIRST, C_T_HEAVY_EMPTY, C_T_LIGHT_EMPTY, C_T_LAST,      // wall-clock marks (100 MHz ticks), kept as maxima: the first three of ~t
+               kNumCounters };
 
 // status bits raised by the checked build
 constexpr uint32_t kFlagBadNodeRef = 1u, kFlagBadTriSlot = 2u, kFlagBadMaterial = 4u, kFlagStackOverflow = 8u,

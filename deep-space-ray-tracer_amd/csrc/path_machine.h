@@ -30,12 +30,14 @@ enum : int {
 // touches L (the next hit's terms, the end of the sample), i.e. in the reference's order; at most one delegated ray per path
 // is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
 // the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
-//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding;
+//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding; bits 9-10: priority level;
 //              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`;
 //              bits 24-31: probe launch only: rays traced for the current pixel (saturating)
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
+constexpr int kHotBit = 9;                   // bits 9-10: rng_mode 0: issue-priority level of the pixel this lane is working on
+constexpr uint32_t kHotMask = 3u << kHotBit;
 
 // Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
 // the DS unit retires a wave's operations in order, so no hardware instruction is needed; what IS needed is that the compiler
@@ -73,10 +75,20 @@ __device__ __forceinline__ void flush_counters(const RenderArgs& args, uint32_t*
     if (COUNT) {
 #pragma unroll
         for (int i = 0; i < kNumCounters; ++i) {
+            if (i >= C_T_FIRST) continue;                       // time marks: written where they happen (mark_time)
             if (i == C_MAX_STACK) atomicMax((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
             else if (c[i]) atomicAdd((unsigned long long*)&args.counters[i], (unsigned long long)c[i]);
             if (i != C_MAX_STACK) c[i] = 0;
         }
+    }
+}
+
+// Counting build: the earliest (first three marks, stored inverted) or latest moment any lane passed a point of the launch.
+template <bool COUNT>
+__device__ __forceinline__ void mark_time(const RenderArgs& args, int which) {
+    if (COUNT) {
+        const unsigned long long t = wall_clock64();
+        atomicMax((unsigned long long*)&args.counters[which], which == C_T_LAST ? t : ~t);
     }
 }
 
@@ -431,8 +443,11 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
         const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
-        // (pixels of the light tiles are one item each, unless an item could then exceed the 4095 samples its 32-bit integer sums hold)
-        const uint32_t per_pixel_light = (RNGMODE == 1 && spp > 4095) ? per_pixel : 1u;
+        // Pixels of the light tiles are sliced like the heavy ones.  (They were one item each until the queue marks of the counting build
+        // -- DsrtStats.heavy_queue_empty_ms -- showed what that did: the light queue is served last, and a 1000-sample item of cheap
+        // samples is a longer job than a 125-sample item of dear ones, so the biggest jobs came last: one rank's share of an 8-GPU
+        // frame spent 178 of its 316 ms (counting build) after the heavy queue had run dry.)
+        const uint32_t per_pixel_light = (RNGMODE == 1 && !(args.steal & 4)) ? per_pixel : ((RNGMODE == 1 && spp > 4095) ? per_pixel : 1u);
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt * per_pixel_light;
         bool heavy = PROBE || (ln.aux & 63u) < spread;
         uint32_t item;
@@ -445,6 +460,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         } else {
             if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);   // (uniform address per branch:
             if (item >= (heavy ? heavy_items : light_items)) {                                          //  one atomic per wave)
+                mark_time<COUNT>(args, heavy ? C_T_HEAVY_EMPTY : C_T_LIGHT_EMPTY);
                 heavy = !heavy;
                 if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);
             }
@@ -453,6 +469,17 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const bool sliced = RNGMODE == 1 && pp > 1u;
         ln.chunk = 0;
         const bool none = item >= (heavy ? heavy_items : light_items);
+        if constexpr (!PROBE && RNGMODE == 0) {
+            // Issue priority for the long chains (render_body raises the wave's s_setprio while it holds one): how far up the
+            // costliest-first order this pixel's tile stands, as a level 0-3.
+            ln.aux &= ~kHotMask;
+            if (args.hot_shift > 0 && heavy && !none) {
+                const uint32_t r = item / tt, base = n_heavy >> (args.hot_shift - 1);
+                uint32_t level = r < base ? 1u : 0u;
+                if (args.hot_graded) level += (r < (base >> 2) ? 1u : 0u) + (r < (base >> 4) ? 1u : 0u); else level *= 3u;
+                ln.aux |= level << kHotBit;
+            }
+        }
         if (sliced) { ln.chunk = item % pp; item /= pp; }
         if (!heavy) item += n_heavy * tt;                     // position in tile_order x pixels per tile
         if (none) {

@@ -96,6 +96,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 #pragma unroll
     for (int i = 0; i < kNumCounters; ++i) c[i] = 0;
     uint32_t flags = 0;
+    const unsigned long long t_enter = COUNT ? wall_clock64() : 0ull;
+    if (lane == 0) mark_time<COUNT>(args, C_T_FIRST);
     float* const pool_base = POOLCOST ? args.pool_probe + glane : nullptr;
     const size_t pool_stride = (size_t)gridDim.x * blockDim.x;
     if (POOLCOST) poolcost_store(ln, pool_base, pool_stride);
@@ -125,6 +127,18 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
         }
 
         if (wave_all(state == ST_DONE)) break;
+
+        if constexpr (!PROBE && RNGMODE == 0) {
+            // Waves that hold a pixel of a heavy tile ask the SIMD's arbiter for priority over waves that only hold background pixels
+            // (levels: device_api.hip).  Scheduling only.
+            if (args.hot_shift > 0) {
+                const uint32_t lv = (ln.aux & kHotMask) >> kHotBit;
+                if (wave_any(lv == 3u)) __builtin_amdgcn_s_setprio(3);
+                else if (wave_any(lv == 2u)) __builtin_amdgcn_s_setprio(2);
+                else if (wave_any(lv == 1u)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
 
         // =====================================================================================
         // TRAVERSE phase ("while-while"), written flat: per wave iteration every lane that is descending performs at most
@@ -280,6 +294,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
         }
     }
 
+    if (COUNT && lane == 0) c[C_WAVE_TICKS] = (uint32_t)(wall_clock64() - t_enter);
+    if (lane == 0) mark_time<COUNT>(args, C_T_LAST);
     flush_counters<COUNT>(args, c);
     if (flags) atomicOr(args.flags, flags);
 }

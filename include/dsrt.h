@@ -183,7 +183,9 @@ typedef struct DsrtRenderDesc {
                                        +64 = 8 probe samples instead of 4; +128 = the state-move cost experiment;
                                        bits 8-19 = rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass);
                                        bits 20-21 = probe order when every heavy pixel starts at once: 0 = dealt costliest / cheapest
-                                       alternately, 1 = coverage order kept, 2 = plain costliest first; +(1 << 22) = probe one pixel in four}
+                                       alternately, 1 = coverage order kept, 2 = plain costliest first; +(1 << 22) = probe one pixel in four;
+                                       bits 23-25 = rng_mode 0 issue priority: 0 = waves holding a heavy tile's pixel run above the rest,
+                                       7 = off, 2-6 = finer grades (experiments); bit 31 = rng_mode 1: background pixels unsliced}
                                        (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 
@@ -203,6 +205,11 @@ typedef struct DsrtStats {
     uint64_t visits_depth_lt6, visits_depth_lt9, visits_depth_lt12;
     /* tiles of this shard / tiles the pre-pass proved empty and left out (their pixels are exactly black) */
     uint64_t tiles_total, tiles_culled;
+    /* counting build: sum over the waves of the time each spent in the kernel, in ticks of the 100 MHz wall clock; divided by
+     * (waves_launched x kernel time) it is the fraction of the launch the average wave was resident */
+    uint64_t wave_ticks;
+    /* counting build, ms after the first wave started: the heavy / the light work queue handed out its last item, the last wave left */
+    float    heavy_queue_empty_ms, light_queue_empty_ms, last_wave_exit_ms;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of

@@ -369,13 +369,13 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
     scene = hs.view(cam, SUN)
     want_rgb, want_f32, _ = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 40, 64, 128, 1 << 20, 2 << 20, 1 << 22, (1 << 22) + 32 + (2 << 20)):
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 40, 64, 128, 1 << 20, 2 << 20, 1 << 22, (1 << 22) + 32 + (2 << 20), 3 << 23, (1 << 26) + (1 << 23)):
         # (128: the path-state round trip of the pool-cost experiment; 1 << 20 and up: probe variants, include/dsrt.h)
         rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
     # rng_mode 1 sums samples as integers, so neither the scheduling switches nor sample stealing (+16 switches it off) may move a bit
     a, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
-    for flags in (12, 16, 28, 1 + 16, 2):
+    for flags in (12, 16, 28, 1 + 16, 2, -(1 << 31)):
         b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, flags)))
         assert np.array_equal(a, b), flags
 

@@ -58,7 +58,8 @@ def main():
             extra = {"counting_ms": round(sc.kernel_ms, 1), "samples": sc.samples, "rays": sc.rays, "util_node": round(sc.internal_entered / max(1, sc.node_slots), 3),
                      "util_adv": round(sc.adv_active / max(1, sc.adv_slots), 3),
                      "node_idle_leaf_wait_done": [round(sc.idle_at_leaf / max(1, sc.node_slots), 3), round(sc.idle_waiting / max(1, sc.node_slots), 3), round(sc.idle_done / max(1, sc.node_slots), 3)],
-                     "wave_iters_node_tri_adv": [sc.node_slots // 64, sc.tri_slots // 64, sc.adv_slots // 64]}
+                     "wave_iters_node_tri_adv": [sc.node_slots // 64, sc.tri_slots // 64, sc.adv_slots // 64],
+                     "queues_empty_heavy_light_last_exit_ms": [round(sc.heavy_queue_empty_ms, 1), round(sc.light_queue_empty_ms, 1), round(sc.last_wave_exit_ms, 1)], "waves": sc.waves_launched, "mean_wave_residency": round(sc.wave_ticks / 1e5 / max(1e-9, sc.kernel_ms) / max(1, sc.waves_launched), 3)}
         worst = max(times)
         base = worst if base is None else base
         print(json.dumps({"frame": a.frame, "rng_mode": a.rng, "bvh": a.bvh, "shards": n, "tune": a.tune, "ranks_timed": ranks, "kernel_ms": [round(t, 2) for t in times],
