@@ -220,7 +220,7 @@ def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, 
     frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
     mine = sequence.frame_assignment(frames, rank, world, args.split)
     shard = (rank, world, shard_mod.gather_to_root) if (world > 1 and args.split == "tiles") else None
-    pipe = sequence.FramePipeline(d, ctx, W, H, spp, depth, inflight=args.inflight, rng_mode=args.rng_mode, device=dev, shard=shard)
+    pipe = sequence.FramePipeline(d, ctx, W, H, spp, depth, inflight=args.inflight, rng_mode=args.rng_mode, device=dev, shard=shard, tune=(0, 0, 0, args.tune3))
 
     def go(ids):
         for i in ids:
@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
+    ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

@@ -73,6 +73,7 @@ struct FrameParams {
     uint32_t seed32;
     uint32_t seed_hi;          // rng_mode 1: upper half of the 64-bit seed (Philox key.y)
     int   chunks, chunk_len;   // rng_mode 1: a pixel's spp samples are split into `chunks` work items of `chunk_len` samples
+    int   light_chunk_len;     // rng_mode 1: samples per work item of a background pixel (path_machine.h, ST_FETCH)
     int   tile;                // tile edge in pixels (multiple of 8)
     int   tiles_x, tiles_y;
     int   shard_rank, shard_count;

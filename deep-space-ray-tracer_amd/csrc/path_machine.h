@@ -443,11 +443,11 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
         const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
-        // Pixels of the light tiles are sliced like the heavy ones.  (They were one item each until the queue marks of the counting build
-        // -- DsrtStats.heavy_queue_empty_ms -- showed what that did: the light queue is served last, and a 1000-sample item of cheap
-        // samples is a longer job than a 125-sample item of dear ones, so the biggest jobs came last: one rank's share of an 8-GPU
-        // frame spent 178 of its 316 ms (counting build) after the heavy queue had run dry.)
-        const uint32_t per_pixel_light = (RNGMODE == 1 && !(args.steal & 4)) ? per_pixel : ((RNGMODE == 1 && spp > 4095) ? per_pixel : 1u);
+        // Pixels of the light tiles are cut into items of P.light_chunk_len samples (host: dsrt_render).  They were one item each until the
+        // queue marks of the counting build -- DsrtStats.heavy_queue_empty_ms -- showed what that did: the light queue is served last, and
+        // a 1000-sample item of cheap samples is a longer job than a 125-sample item of dear ones, so the biggest jobs came last.
+        const int light_len = RNGMODE == 1 ? P.light_chunk_len : spp;
+        const uint32_t per_pixel_light = RNGMODE == 1 ? (uint32_t)((spp + light_len - 1) / light_len) : 1u;
         const uint32_t heavy_items = n_heavy * tt * per_pixel, light_items = (n_live - n_heavy) * tt * per_pixel_light;
         bool heavy = PROBE || (ln.aux & 63u) < spread;
         uint32_t item;
@@ -505,8 +505,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     sample = 0;
                     ln.sample_end = spp;
                 } else {
-                    sample = sliced ? (int)ln.chunk * chunk_len : 0;
-                    ln.sample_end = sliced ? min(spp, sample + chunk_len) : spp;
+                    const int len = heavy ? chunk_len : light_len;
+                    sample = sliced ? (int)ln.chunk * len : 0;
+                    ln.sample_end = sliced ? min(spp, sample + len) : spp;
                     restream();
                 }
                 state = ST_GEN;

@@ -27,10 +27,11 @@ class FramePipeline:
     frame first); `drain()` waits for everything.  `on_frame(i, host_uint8_tensor)` is called when a frame's image has landed in
     pinned host memory (the tensor is reused by later frames: copy it if you keep it)."""
 
-    def __init__(self, d, ctx, W, H, spp, depth, inflight=4, rng_mode=0, device=None, shard=None, on_frame=None):
+    def __init__(self, d, ctx, W, H, spp, depth, inflight=4, rng_mode=0, device=None, shard=None, on_frame=None, tune=(0, 0, 0, 0)):
         import torch
         self.torch, self.d = torch, d
         self.W, self.H, self.spp, self.depth, self.rng_mode = W, H, spp, depth, rng_mode
+        self.tune = tuple(tune)                                       # scheduling knobs of DsrtRenderDesc (experiments; none changes a pixel)
         self.dev = device if device is not None else torch.device("cuda", ctx.device)
         self.K = max(1, int(inflight))
         self.ctxs = [ctx] + [ctx.clone() for _ in range(1, self.K)]
@@ -68,9 +69,9 @@ class FramePipeline:
         c.set_camera_sun(camera, tuple(sun_dir))
         if self.shard:
             rank, world, gather = self.shard
-            desc = d.make_desc(self.W, self.H, self.spp, self.depth, shard_rank=rank, shard_count=world, rng_mode=self.rng_mode)
+            desc = d.make_desc(self.W, self.H, self.spp, self.depth, shard_rank=rank, shard_count=world, rng_mode=self.rng_mode, tune=self.tune)
         else:
-            desc = d.make_desc(self.W, self.H, self.spp, self.depth, rng_mode=self.rng_mode)
+            desc = d.make_desc(self.W, self.H, self.spp, self.depth, rng_mode=self.rng_mode, tune=self.tune)
         with torch.cuda.stream(stream):                               # everything of this frame is ordered on its slot's stream
             target = self.parts[slot] if self.shard else self.images[slot]
             c.render(desc, target.data_ptr(), stream=stream.cuda_stream)
