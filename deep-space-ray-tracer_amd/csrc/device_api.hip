@@ -509,7 +509,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
     a.helpers = (desc->tune[3] & 4) ? 0 : 1;
-    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0);
+    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0) | ((desc->tune[3] & (1 << 27)) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
     // Interleaved medians, 1080p x 1000: near frame 1117 -> 1108 ms, frame 95 801 -> 785 ms.  Finer grades (the top quarter and sixteenth of
     // the order above the rest) move nothing consistently: near frame 1103, frame 95 801; one of 8 shares 543 ms with every setting -- a

@@ -186,7 +186,9 @@ typedef struct DsrtRenderDesc {
                                        alternately, 1 = coverage order kept, 2 = plain costliest first; +(1 << 22) = probe one pixel in four;
                                        bits 23-25 = rng_mode 0 issue priority: 0 = waves holding a heavy tile's pixel run above the rest,
                                        7 = off, 2-6 = finer grades (experiments); bits 28-29 = rng_mode 1: least samples per work item of a
-                                       background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512; bit 31 = background pixels one item each}
+                                       background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512; bit 31 = background pixels one item each;
+                                       bit 27 = counting build of rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as
+                                       bit patterns, 100 MHz ticks, instead of the colour (tools/chain_timeline.py)}
                                        (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
 } DsrtRenderDesc;
 

@@ -543,6 +543,11 @@ def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
         assert np.array_equal(f32.view(np.uint32), want32.view(np.uint32)), frame
         if frame == 70:
             assert st.tiles_culled > 0.8 * st.tiles_total
+        else:
+            # the priority switches only exist on a chip full of heavy work, i.e. at this size: scheduling only, so the same bits
+            for flags in (7 << 23, (1 << 26) + (3 << 23)):
+                again, again32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, tune=(0, 0, 0, flags)), want_f32=True)
+                assert np.array_equal(again, want) and np.array_equal(again32.view(np.uint32), want32.view(np.uint32)), flags
 
 
 def _station_scene(dsrt, tmp_path, tris):
