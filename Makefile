@@ -14,7 +14,7 @@ CXX      ?= g++
 ARCH     ?= gfx950
 BUILD    := build
 
-HOST_SRC := $(PKG)/host/obj_mesh.cpp $(PKG)/host/image_io.cpp $(PKG)/host/jpeg_decode.cpp $(PKG)/host/scene_flatten.cpp $(PKG)/host/bvh_median.cpp $(PKG)/host/bvh_sah.cpp $(PKG)/host/pose_camera.cpp
+HOST_SRC := $(PKG)/host/obj_mesh.cpp $(PKG)/host/image_io.cpp $(PKG)/host/jpeg_decode.cpp $(PKG)/host/bmp_tga_decode.cpp $(PKG)/host/scene_flatten.cpp $(PKG)/host/bvh_median.cpp $(PKG)/host/bvh_sah.cpp $(PKG)/host/pose_camera.cpp
 HIP_SRC  := $(PKG)/csrc/render_kernel.hip $(PKG)/csrc/device_api.hip $(PKG)/csrc/microbench.hip $(PKG)/csrc/multi_gpu.hip $(PKG)/csrc/bvh_lbvh.hip
 HOST_OBJ := $(patsubst $(PKG)/host/%.cpp,$(BUILD)/host_%.o,$(HOST_SRC))
 HIP_OBJ  := $(patsubst $(PKG)/csrc/%.hip,$(BUILD)/hip_%.o,$(HIP_SRC))

@@ -30,6 +30,8 @@ struct RgbImage {
 };
 bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img);
 bool decode_jpeg(const std::vector<uint8_t>& file_bytes, RgbImage& img);      // jpeg_decode.cpp
+bool decode_bmp(const std::vector<uint8_t>& file_bytes, RgbImage& img);       // bmp_tga_decode.cpp
+bool decode_tga(const std::vector<uint8_t>& file_bytes, RgbImage& img);
 
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);

@@ -1,12 +1,11 @@
-// image_io.cpp -- texture decode (PNM, PNG here; JPEG in jpeg_decode.cpp) to 8-bit RGB, and the P6 / PNG writers.
+// image_io.cpp -- texture decode (PNM, PNG here; JPEG in jpeg_decode.cpp; BMP and TGA in bmp_tga_decode.cpp) to 8-bit RGB, and the P6 / PNG writers.
 //
 // The reference decodes textures with its vendored stb_image forced to 3 channels
 // (src/gpu_scene_builder.cpp:215) and writes frames as binary PPM (src/gpu_render.cu:1099-1107).
-// This file is an independent implementation of the two container formats we can support without
-// third-party code: binary/ASCII PNM, non-interlaced PNG (inflate through the system zlib) and baseline /
-// progressive JPEG (jpeg_decode.cpp).  Any other format (BMP, TGA, GIF, PSD, interlaced PNG, CMYK JPEG) is a load
-// failure, for which the reference's own behaviour is a 1x1 white texture plus a warning
-// (src/gpu_scene_builder.cpp:216-221); the builder does the same and reports it (dsrt_host_scene_texture_failures).
+// This file is an independent implementation of the container formats we can support without
+// third-party code: binary/ASCII PNM and PNG, interlaced or not (inflate through the system zlib).  What is left out of the reference
+// decoder's list -- GIF, PSD, PIC, Radiance HDR, CMYK JPEG -- is a load failure, for which the reference's own behaviour is a 1x1 white
+// texture plus a warning (src/gpu_scene_builder.cpp:216-221); the builder does the same and reports it (dsrt_host_scene_texture_failures).
 // Channel handling matches stb's req_comp = 3: gray is replicated, alpha is dropped, 16-bit keeps the
 // high byte, palette entries are expanded.
 #include "host_internal.hpp"
@@ -127,54 +126,75 @@ bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
         else if (!std::memcmp(tag, "IEND", 4)) seen_end = true;
         pos += 12 + (size_t)len;
     }
-    if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || interlace != 0) return false;
+    if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || interlace > 1) return false;
     if ((unsigned long long)w * (unsigned long long)h > kMaxTexturePixels) return false;
     int channels;
     switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break;
                      case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
     const size_t bits_pp = (size_t)channels * depth;
-    const size_t stride = (w * bits_pp + 7) / 8;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    // The image is one pass, or (interlace method 1, Adam7) seven: pass p holds the pixels (x0 + i * dx, y0 + j * dy), as an image of its
+    // own with its own scanlines and filter state; empty passes take no bytes.
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    const Pass* passes = interlace ? adam7 : whole;
+    const int n_passes = interlace ? 7 : 1;
+    size_t raw_size = 0;
+    for (int p = 0; p < n_passes; ++p) {
+        const uint32_t pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+        if (w <= passes[p].x0 || h <= passes[p].y0 || pw == 0 || ph == 0) continue;
+        raw_size += (((size_t)pw * bits_pp + 7) / 8 + 1) * ph;
+    }
     // deflate expands by at most ~1032:1: an IDAT stream that cannot produce the claimed image is rejected before allocating
-    if ((unsigned long long)(stride + 1) * h > (unsigned long long)idat.size() * 1032ull + 1024ull) return false;
-    std::vector<uint8_t> raw((stride + 1) * h);
+    if ((unsigned long long)raw_size > (unsigned long long)idat.size() * 1032ull + 1024ull) return false;
+    std::vector<uint8_t> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
 
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
     img.width = (int)w;
     img.height = (int)h;
     img.rgb.resize((size_t)w * h * 3);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* line = &raw[(stride + 1) * y];
-        const int filter = line[0];
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = line[1 + i];
-            switch (filter) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
-                              case 4: v += paeth(a, b, c); break; default: return false; }
-            cur[i] = (uint8_t)v;
-        }
-        for (uint32_t x = 0; x < w; ++x) {
-            uint8_t s[4] = {0, 0, 0, 0};
-            for (int k = 0; k < channels; ++k) {
-                if (depth >= 8) s[k] = cur[(x * channels + k) * (depth / 8)];
-                else {
-                    const size_t bit = (size_t)x * depth;
-                    const int v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
-                    s[k] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
-                }
+    size_t at = 0;
+    for (int p = 0; p < n_passes; ++p) {
+        const Pass& ps = passes[p];
+        if (w <= ps.x0 || h <= ps.y0) continue;
+        const uint32_t pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw == 0 || ph == 0) continue;
+        const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (uint32_t y = 0; y < ph; ++y) {
+            const uint8_t* line = &raw[at];
+            at += stride + 1;
+            const int filter = line[0];
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int v = line[1 + i];
+                switch (filter) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) / 2; break;
+                                  case 4: v += paeth(a, b, c); break; default: return false; }
+                cur[i] = (uint8_t)v;
             }
-            uint8_t* o = &img.rgb[((size_t)y * w + x) * 3];
-            if (ctype == 3) {
-                const size_t e = (size_t)s[0] * 3;
-                if (e + 2 < palette.size()) { o[0] = palette[e]; o[1] = palette[e + 1]; o[2] = palette[e + 2]; }
-                else o[0] = o[1] = o[2] = 0;
-            } else if (channels <= 2) o[0] = o[1] = o[2] = s[0];
-            else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+            for (uint32_t x = 0; x < pw; ++x) {
+                uint8_t s[4] = {0, 0, 0, 0};
+                for (int k = 0; k < channels; ++k) {
+                    if (depth >= 8) s[k] = cur[(x * channels + k) * (depth / 8)];
+                    else {
+                        const size_t bit = (size_t)x * depth;
+                        const int v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+                        s[k] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+                    }
+                }
+                uint8_t* o = &img.rgb[((size_t)(ps.y0 + y * ps.dy) * w + (ps.x0 + x * ps.dx)) * 3];
+                if (ctype == 3) {
+                    const size_t e = (size_t)s[0] * 3;
+                    if (e + 2 < palette.size()) { o[0] = palette[e]; o[1] = palette[e + 1]; o[2] = palette[e + 2]; }
+                    else o[0] = o[1] = o[2] = 0;
+                } else if (channels <= 2) o[0] = o[1] = o[2] = s[0];
+                else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+            }
+            prev.swap(cur);
         }
-        prev.swap(cur);
     }
     return true;
 }
@@ -184,7 +204,8 @@ bool decode_png(const std::vector<uint8_t>& f, RgbImage& img) {
 bool load_rgb8(const std::string& path, bool flip_vertically, RgbImage& img) {
     std::vector<uint8_t> f;
     if (!read_file(path, f)) return false;
-    if (!decode_png(f, img) && !decode_pnm(f, img) && !decode_jpeg(f, img)) return false;
+    // the reference decoder's own order of attempts: PNG, BMP, (GIF, PSD, PIC: not supported here), JPEG, PNM, (HDR), TGA last -- it has no signature
+    if (!decode_png(f, img) && !decode_bmp(f, img) && !decode_jpeg(f, img) && !decode_pnm(f, img) && !decode_tga(f, img)) return false;
     if (flip_vertically) {
         const size_t row = (size_t)img.width * 3;
         std::vector<uint8_t> tmp(row);

@@ -223,3 +223,54 @@ def test_damaged_jpegs_fail_cleanly(dsrt, tmp_path):
             except dsrt.DsrtError:
                 refused += 1
     assert tried > 250 and refused > 20
+
+
+def _image_fixtures():
+    ref = json.load(open(os.path.join(GOLDEN, "ref_stb_decode_images.json")))
+    return [(name, os.path.join(ASSETS, "images", name), r) for name, r in sorted(ref.items())]
+
+
+def test_bmp_tga_and_interlaced_png_give_the_texels_of_the_reference_stb_image(dsrt):
+    """The other containers a map_Kd can name (the reference's stb_image sniffs the content, src/gpu_scene_builder.cpp:215): host/bmp_tga_decode.cpp
+    and the Adam7 path of host/image_io.cpp against what the reference's own stb build made of 65 files written byte by byte by
+    tests/golden/make_image_fixtures.py -- BMP with 12 / 40 / 108 / 124-byte headers, 1 / 4 / 8-bit palettes, 16 / 32 bits with default and BITFIELDS
+    masks (3- to 8-bit fields), top-down, a gap before the pixels; TGA types 1 / 2 / 3 / 9 / 10 / 11, 8 to 32 bits, colour maps of 16 / 24 / 32
+    bits, 16-bit indices, both row orders; PNG of every colour type and bit depth, interlaced and not, including images whose first Adam7
+    passes are empty.  Same bytes where the reference decodes, a refusal where it refuses (run-length BMP, 10-bit fields)."""
+    kinds = set()
+    for name, path, r in _image_fixtures():
+        kinds.add(name.split("_")[0].rstrip("0123456789") + ("+adam7" if "adam7" in name else ""))
+        if not r["ok"]:
+            with pytest.raises(dsrt.DsrtError):
+                dsrt.decode_image_file(path)
+            continue
+        want = np.frombuffer(bytes.fromhex(r["rgb"]), np.uint8).reshape(r["h"], r["w"], 3)
+        got = dsrt.decode_image_file(path)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        assert np.array_equal(dsrt.decode_image_file(path, flip_vertically=True), want[::-1]), name
+    assert {"bmp", "tga", "png", "png+adam7"} <= kinds and len(_image_fixtures()) >= 60
+
+
+def test_damaged_bmp_tga_png_fail_cleanly(dsrt, tmp_path):
+    """As for the JPEGs: cut and corrupted files are refused or decode to an image of bounded size, whatever their headers claim."""
+    rng = np.random.default_rng(11)
+    tried = refused = 0
+    picks = [f for f in _image_fixtures() if f[2]["ok"]][::3]
+    for name, path, r in picks:
+        raw = bytearray(open(path, "rb").read())
+        variants = [raw[:n] for n in (0, 1, 2, 10, 17, 18, 30, len(raw) // 2, len(raw) - 1)]
+        for _ in range(25):
+            v = bytearray(raw)
+            for _ in range(int(rng.integers(1, 5))):
+                v[int(rng.integers(0, min(len(v), 64)))] = int(rng.integers(0, 256))        # headers live in the first bytes
+            variants.append(v)
+        for v in variants:
+            p = tmp_path / ("x." + name.rsplit(".", 1)[1])
+            p.write_bytes(bytes(v))
+            tried += 1
+            try:
+                img = dsrt.decode_image_file(p)
+                assert img.ndim == 3 and img.shape[2] == 3 and img.size <= (1 << 28) * 3
+            except dsrt.DsrtError:
+                refused += 1
+    assert tried > 500 and refused > 50
