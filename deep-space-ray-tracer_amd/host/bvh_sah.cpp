@@ -136,6 +136,20 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
             centroid[3 * i + a] = 0.5f * (tri_box[i].lo[a] + tri_box[i].hi[a]);
         }
     }
+    // A triangle that lies in an axis plane has a box of zero thickness, and a leaf of such triangles a box the reference's slab test can
+    // never hit (t_max <= t_min holds with equality, src/gpu_render.cu:312) -- in the reference's own tree such faces survive or vanish by
+    // the accident of who shares their leaf.  A builder that is free to choose must not make geometry vanish: flat triangle boxes are
+    // widened by 2^-12 of the scene's extent on that axis, enough to survive the rounding of (box - origin) for any camera within 2,000
+    // scene extents.  The median builder keeps the reference's boxes, accidents included.
+    {
+        float lo[3] = {tri_box[0].lo[0], tri_box[0].lo[1], tri_box[0].lo[2]}, hi[3] = {tri_box[0].hi[0], tri_box[0].hi[1], tri_box[0].hi[2]};
+        for (size_t i = 1; i < n; ++i)
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tri_box[i].lo[a]); hi[a] = fmaxf(hi[a], tri_box[i].hi[a]); }
+        const float pad = dsrt::flat_box_pad(fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]));
+        for (size_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a)
+                if (tri_box[i].lo[a] == tri_box[i].hi[a]) { tri_box[i].lo[a] -= pad; tri_box[i].hi[a] += pad; }
+    }
     hs->tri_indices.resize(n);
     for (size_t i = 0; i < n; ++i) hs->tri_indices[i] = (int)i;
     hs->nodes.reserve(n);

@@ -33,6 +33,9 @@ bool decode_jpeg(const std::vector<uint8_t>& file_bytes, RgbImage& img);      //
 bool decode_bmp(const std::vector<uint8_t>& file_bytes, RgbImage& img);       // bmp_tga_decode.cpp
 bool decode_tga(const std::vector<uint8_t>& file_bytes, RgbImage& img);
 
+// half-width by which the non-parity BVH builders (bvh_sah.cpp, csrc/bvh_lbvh.hip) widen a triangle box that has zero thickness on an axis
+inline float flat_box_pad(float scene_extent) { return scene_extent > 0.0f ? scene_extent * (1.0f / 4096.0f) : 1.0e-6f; }
+
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);
 

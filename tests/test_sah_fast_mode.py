@@ -25,6 +25,24 @@ def _load(dsrt, world, kind):
     return hs
 
 
+def _flat_pad(verts):
+    """host_internal.hpp flat_box_pad: the non-parity builders widen a triangle box that has zero thickness on an axis by this much to either side
+    (a leaf box of zero thickness is never hit by the reference's slab test)."""
+    ext = np.float32((verts.reshape(-1, 3).max(axis=0) - verts.reshape(-1, 3).min(axis=0)).max())
+    return np.float32(ext * np.float32(1.0 / 4096.0)) if ext > 0 else np.float32(1e-6)
+
+
+def _assert_tight(v, nd, pad):
+    """Leaf box = the exact float bounds of its triangles, each triangle's own box first widened by `pad` on an axis where it is flat."""
+    tri = v.reshape(-1, 3, 3)
+    lo, hi = tri.min(axis=1).astype(np.float32), tri.max(axis=1).astype(np.float32)
+    flat = lo == hi
+    lo = np.where(flat, lo - pad, lo).astype(np.float32)
+    hi = np.where(flat, hi + pad, hi).astype(np.float32)
+    assert np.array_equal(lo.min(axis=0), nd["bbox_min"]) and np.array_equal(hi.max(axis=0), nd["bbox_max"])
+    assert (nd["bbox_max"] > nd["bbox_min"]).all()                        # never a box of zero thickness
+
+
 def _scene(dsrt, name, kind):
     world, cam_args, spp = CASES[name]
     hs = _load(dsrt, world, kind)
@@ -40,6 +58,7 @@ def test_sah_tree_is_a_valid_bvh(dsrt, world):
     nodes, idx, tris = a["nodes"], a["idx"], a["tris"]
     assert sorted(idx.tolist()) == list(range(len(tris)))                 # a permutation: every triangle in exactly one leaf
     verts = tris["v"]                                                     # [N, 3 vertices, xyz]
+    pad = _flat_pad(verts)
     seen_nodes, covered = set(), np.zeros(len(tris), bool)
     todo = [(0, None)]
     while todo:
@@ -55,7 +74,7 @@ def test_sah_tree_is_a_valid_bvh(dsrt, world):
             assert not covered[sl].any()
             covered[sl] = True
             v = verts[sl].reshape(-1, 3)
-            assert np.array_equal(v.min(axis=0), nd["bbox_min"]) and np.array_equal(v.max(axis=0), nd["bbox_max"])   # tight, exact floats
+            _assert_tight(v, nd, pad)
         else:
             assert nd["left"] == n + 1 and nd["right"] > nd["left"]       # pre-order numbering
             todo += [(int(nd["right"]), n), (int(nd["left"]), n)]
@@ -103,6 +122,7 @@ def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(
     nodes, idx, tris = a["nodes"], a["idx"], a["tris"]
     assert sorted(idx.tolist()) == list(range(len(tris)))
     verts = tris["v"]
+    pad = _flat_pad(verts)
     covered, seen, todo = np.zeros(len(tris), bool), set(), [(0, None)]
     while todo:
         n, parent = todo.pop()
@@ -117,7 +137,7 @@ def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(
             assert not covered[sl].any()
             covered[sl] = True
             v = verts[sl].reshape(-1, 3)
-            assert np.array_equal(v.min(axis=0), nd["bbox_min"]) and np.array_equal(v.max(axis=0), nd["bbox_max"])
+            _assert_tight(v, nd, pad)
         else:
             todo += [(int(nd["right"]), n), (int(nd["left"]), n)]
     assert covered.all() and len(seen) == len(nodes) and hs.stack_need <= 64
@@ -128,11 +148,12 @@ def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(
     for key in ("rays", "box_fetches", "nodes_entered", "tri_tests", "hit_updates", "max_stack"):
         assert getattr(st, key) == want_cnt[key], key
     if name != "textured":
-        # (`textured` is a few axis-aligned quads: which of them end up in zero-thickness leaf boxes -- boxes the reference's slab test can
-        # never hit, DESIGN.md section 8 -- depends on the tree, so there the image legitimately differs between builders)
+        # (`textured` is a few axis-aligned quads: in the reference's median tree some of them sit in zero-thickness leaf boxes, which its slab
+        # test can never hit -- DESIGN.md section 8 -- while this builder widens such boxes, so there the images legitimately differ)
         hs_m, scene_m, _, _, _, _ = _scene(dsrt, name, "median")
         med, _, _ = oracle.render(scene_m, W, H)
-        assert (med != want_rgb).any(axis=2).mean() < 0.03 and abs(med.astype(float).mean() - want_rgb.astype(float).mean()) < 0.6
+        # (mean level within 1.5 of 255: in `mixed` one small axis-aligned face that the median tree hides in a flat leaf is visible on this tree)
+        assert (med != want_rgb).any(axis=2).mean() < 0.03 and abs(med.astype(float).mean() - want_rgb.astype(float).mean()) < 1.5
     # deterministic: the same tree twice
     hs2, _, _, _, _, _ = _scene(dsrt, name, "lbvh")
     b = hs2.arrays()
