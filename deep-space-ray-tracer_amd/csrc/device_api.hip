@@ -24,8 +24,6 @@
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
-hipError_t launch_poolcost(const RenderArgs& a, int blocks, hipStream_t stream);
-int poolcost_words();
 hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
@@ -34,7 +32,7 @@ hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipSt
 int kernel_waves_per_block();
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
                              uint32_t resident_lanes, bool cull, hipStream_t stream);
-hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, int small_mode, hipStream_t stream);
+hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream);
 hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
 }  // namespace dsrt
 
@@ -258,7 +256,6 @@ struct DsrtContext {
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp, probe_queue;
     DevBuf<unsigned long long> accum_fixed;
-    DevBuf<float> pool_probe;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t done = nullptr;      // recorded behind every render: the next render on ANY stream waits for it (queue words, spill strip,
     bool done_valid = false;        // pre-pass arrays and partial sums are per context, so a context has one render in flight)
@@ -509,7 +506,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
     a.helpers = (desc->tune[3] & 4) ? 0 : 1;
-    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & 32) ? 2 : 0) | ((desc->tune[3] & (1 << 27)) ? 8 : 0);      // (8: timing image, counting build)
+    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & (1 << 27)) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
     // Interleaved medians, 1080p x 1000: near frame 1117 -> 1108 ms, frame 95 801 -> 785 ms.  Finer grades (the top quarter and sixteenth of
     // the order above the rest) move nothing consistently: near frame 1103, frame 95 801; one of 8 shares 543 ms with every setting -- a
@@ -553,10 +550,9 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
             if (ctx->probe_queue.n < 1024) { int rc = ctx->probe_queue.alloc(1024); if (rc) return rc; }
             HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
             pa.probe_queue = ctx->probe_queue.p;
-            pa.probe_all = (desc->tune[3] & (1 << 22)) ? 0 : 1;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
             HIP_TRY(launch_probe(pa, blocks, stream));
-            HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, (desc->tune[3] >> 20) & 3, stream));       // experiments: 1 = keep the coverage order, 2 = plain sorted order, when all start at once
+            HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, stream));
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
         }
     } else {
@@ -567,12 +563,6 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    if ((desc->tune[3] & 128) && desc->rng_mode == 0 && !count && !desc->checked) {       // experiment: DESIGN.md section 6, render_kernel.hip poolcost_*
-        const size_t words = (size_t)poolcost_words() * (size_t)blocks * (size_t)threads_per_block;
-        if (ctx->pool_probe.n < words) { int rc = ctx->pool_probe.alloc(words); if (rc) return rc; }
-        a.pool_probe = ctx->pool_probe.p;
-        HIP_TRY(launch_poolcost(a, blocks, stream));
-    } else
     HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));

@@ -97,7 +97,6 @@ struct RenderArgs {
     uint32_t* probe_queue;     // probe launch only: 64 queue words, 64 bytes apart (path_machine.h, ST_FETCH)
     int       hot_shift;       // rng_mode 0: 0 = off; s > 0: pixels of the first n_heavy >> (s - 1) tiles of the order raise their wave's issue priority
     int       hot_graded;      //   1 = three levels (that share, a quarter and a sixteenth of it), 0 = one level
-    int       probe_all;       // probe launch only: 1 = every pixel of the heavy tiles, 0 = one in four
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word
@@ -110,7 +109,6 @@ struct RenderArgs {
     int       advance_budget;  // state transitions per lane per advance phase
     int       helpers;         // 1: idle lanes trace shadow rays for busy lanes of their wave (path_machine.h)
     int       steal;           // rng_mode 1: 1 = a lane that is out of work takes over half the remaining samples of a busy lane of its wave
-    float*    pool_probe;      // experiment (tune[3] + 128): [word][global lane] strip the path state makes a round trip through per advance pass
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
 };
 

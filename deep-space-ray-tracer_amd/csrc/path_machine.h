@@ -425,11 +425,10 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         }
         if (PROBE) {                                            // probe launch: what this pixel cost, added to its tile
             const uint32_t g = (uint32_t)((H - 1 - ky) / P.tile) * (uint32_t)P.tiles_x + (uint32_t)(px / P.tile);
-            // a tile's place in the order is decided by its COSTLIEST probed pixel, not by the sum over its pixels: a tile's pixels go
-            // to 64 different lanes, so what the end of the frame waits for is the longest single chain, and that has to start first
-            // (tune[3] + 32 restores the sum; 1080p x 1000 near frame 1161 -> 1127 ms)
-            if (args.steal & 2) atomicAdd(&args.tile_work[g / (uint32_t)P.shard_count], ln.aux >> 24);
-            else atomicMax(&args.tile_work[g / (uint32_t)P.shard_count], ln.aux >> 24);
+            // a tile's place in the order is decided by its COSTLIEST pixel, not by the sum over its pixels: a tile's pixels go to 64
+            // different lanes, so what the end of the frame waits for is the longest single chain, and that has to start first
+            // (keyed by the sum, the near frame took 1176 instead of 1161 ms: profiles/r02/ab_probe_key_max_vs_sum.jsonl)
+            atomicMax(&args.tile_work[g / (uint32_t)P.shard_count], ln.aux >> 24);
             ln.aux &= 0x00FFFFFFu;
         }
         flush_counters<COUNT>(args, c);
@@ -446,8 +445,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // chains it holds, because lanes in different phases take turns.  Only the assignment of pixels to lanes changes.
         // The probe visits the heavy tiles only, every pixel (a tile's place is decided by its costliest pixel, so a sample of its
         // pixels misses it: all against one in four, near frame 1157 -> 1126 ms, spread 1141-1162 -> 1114-1131).
-        const bool probe_all = PROBE && args.probe_all;          // 0 = one pixel in four (even column, even row): an experiment switch
-        const uint32_t tt = (PROBE && !probe_all) ? (uint32_t)(P.tile * P.tile) >> 2 : (uint32_t)(P.tile * P.tile);
+        const uint32_t tt = (uint32_t)(P.tile * P.tile);
         const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
         const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
         const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
@@ -498,9 +496,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
             const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
             const uint32_t per_row = (uint32_t)P.tile >> 3;
-            const bool quarter = PROBE && !probe_all;                                      // even column, even row only
-            const uint32_t sub = quarter ? within >> 4 : within >> 6;                      // which 8x8 block of the tile
-            const uint32_t lx = quarter ? (within & 3u) << 1 : within & 7u, ly = quarter ? ((within >> 2) & 3u) << 1 : (within >> 3) & 7u;
+            const uint32_t sub = within >> 6;                                               // which 8x8 block of the tile
+            const uint32_t lx = within & 7u, ly = (within >> 3) & 7u;
             const uint32_t in_x = (sub % per_row) * 8u + lx, in_y = (sub / per_row) * 8u + ly;
             const int x = (int)(tx * (uint32_t)P.tile + in_x), row = (int)(ty * (uint32_t)P.tile + in_y);
             if (x < W && row < H) {

@@ -38,45 +38,7 @@ constexpr int kWavesPerBlock = 4;
 #define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
-// Experiment behind DESIGN.md section 6 ("what a path pool would cost"): the price of keeping a path's state in global memory instead of
-// registers, measured in isolation.  With POOLCOST every lane that steps its state machine first LOADS 38 words (its 21 words of path
-// state plus 17 standing for the continuation and hit record, which live in LDS / registers today) from a [word][lane] strip and
-// STORES them back after the step -- the traffic, the instruction count and the cache footprint (40 MB per launch) of a pool in which a
-// path's state moves once per ray, with none of the pool's benefit.  Values make an exact round trip, so the image does not change.
-constexpr int kPoolWords = 38;
-// (plain loads and stores through a pointer the compiler cannot see through, so that they pipeline like any others -- `volatile` would make
-// hipcc wait for every access on its own -- and are neither forwarded nor removed)
-__device__ __forceinline__ float* opaque(float* p) { asm volatile("" : "+v"(p)); return p; }
-__device__ __forceinline__ void poolcost_store(const Lane& ln, float* base, size_t stride) {
-    float* p = opaque(base);
-    const float w[21] = {__int_as_float(ln.px), __int_as_float(ln.ky), __int_as_float(ln.sample), __int_as_float(ln.depth), __uint_as_float(ln.out_index),
-                         __uint_as_float(ln.rng), ln.accum.x, ln.accum.y, ln.accum.z, ln.thr.x, ln.thr.y, ln.thr.z, ln.L.x, ln.L.y, ln.L.z,
-                         ln.ro.x, ln.ro.y, ln.ro.z, ln.rd.x, ln.rd.y, ln.rd.z};
-#pragma unroll
-    for (int i = 0; i < 21; ++i) p[(size_t)i * stride] = w[i];
-#pragma unroll
-    for (int i = 21; i < kPoolWords; ++i) p[(size_t)i * stride] = ln.closest;
-}
-__device__ __forceinline__ void poolcost_load(Lane& ln, float* base, size_t stride) {
-    const float* p = opaque(base);
-    // straight into the registers the fields live in (no second copy of the state), the stand-in words four at a time
-    ln.px = __float_as_int(p[0 * stride]); ln.ky = __float_as_int(p[1 * stride]); ln.sample = __float_as_int(p[2 * stride]); ln.depth = __float_as_int(p[3 * stride]);
-    ln.out_index = __float_as_uint(p[4 * stride]); ln.rng = __float_as_uint(p[5 * stride]);
-    ln.accum.x = p[6 * stride]; ln.accum.y = p[7 * stride]; ln.accum.z = p[8 * stride];
-    ln.thr.x = p[9 * stride]; ln.thr.y = p[10 * stride]; ln.thr.z = p[11 * stride];
-    ln.L.x = p[12 * stride]; ln.L.y = p[13 * stride]; ln.L.z = p[14 * stride];
-    ln.ro.x = p[15 * stride]; ln.ro.y = p[16 * stride]; ln.ro.z = p[17 * stride];
-    ln.rd.x = p[18 * stride]; ln.rd.y = p[19 * stride]; ln.rd.z = p[20 * stride];
-    float sink = 0.0f;
-    for (int i = 21; i + 4 <= kPoolWords; i += 4) {
-        const float a = p[(size_t)i * stride], b = p[(size_t)(i + 1) * stride], c = p[(size_t)(i + 2) * stride], d = p[(size_t)(i + 3) * stride];
-        sink += (a + b) + (c + d);
-    }
-    sink += p[(size_t)(kPoolWords - 1) * stride];
-    asm volatile("" :: "v"(sink));
-}
-
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool POOLCOST = false>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -98,9 +60,6 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
     uint32_t flags = 0;
     const unsigned long long t_enter = COUNT ? wall_clock64() : 0ull;
     if (lane == 0) mark_time<COUNT>(args, C_T_FIRST);
-    float* const pool_base = POOLCOST ? args.pool_probe + glane : nullptr;
-    const size_t pool_stride = (size_t)gridDim.x * blockDim.x;
-    if (POOLCOST) poolcost_store(ln, pool_base, pool_stride);
 
     for (;;) {
         // =====================================================================================
@@ -120,9 +79,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
             if (state < ST_TRAV_CLOSEST || state == ST_DONE) {
-                if (POOLCOST) poolcost_load(ln, pool_base, pool_stride);
                 advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE>(ln, args, c, flags);
-                if (POOLCOST) poolcost_store(ln, pool_base, pool_stride);
             }
         }
 
@@ -305,10 +262,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
     render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false>(args);
 }
 
-__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_poolcost_kernel(const RenderArgs args) {
-    render_body<8, false, false, true, 0, false, true>(args);
-}
-
 // The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
 // tile's entry of args.tile_work.  Its own kernel symbol, so that profiles keep it apart from the frame's launch.
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_probe_kernel(const RenderArgs args) {
@@ -472,7 +425,7 @@ __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* _
 // entries of `order` -- are re-sorted by it, most work first, so the pixels with the longest serial sample chains start at
 // once instead of wherever their tile's coverage count put them.  Scheduling only.
 __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, uint32_t* __restrict__ tmp,
-                                                                 const uint32_t* __restrict__ sched, int small_mode) {
+                                                                 const uint32_t* __restrict__ sched) {
     __shared__ uint32_t bins[256], cursor[256], wmax;
     const uint32_t n = sched[0];
     // Fewer heavy pixels than resident lanes (a mid-distance frame; one rank's share): every heavy pixel starts in the first instant
@@ -482,7 +435,6 @@ __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t*
     // no probe): frame 75 387 / 361 / 374 / 374 ms, frame 85 400 / 388 / 368 / 373, frame 90 505 / 500 / 512 / 479, one of 8 shares of
     // the near frame 564 / 563 / 625 / 610 (profiles/r02/ab_small_regime_order.jsonl); one setting spreads +-5 % on such frames.
     const bool all_start_at_once = sched[2] < 64u;
-    if (all_start_at_once && small_mode == 1) return;       // experiment: keep the coverage order
     for (int b = threadIdx.x; b < 256; b += blockDim.x) bins[b] = 0;
     if (threadIdx.x == 0) wmax = 1u;
     __syncthreads();
@@ -500,7 +452,7 @@ __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t*
         const uint32_t t = tmp[i];
         order[atomicAdd(&cursor[255u - (uint32_t)((unsigned long long)work[t] * 255ull / top)], 1u)] = t;
     }
-    if (all_start_at_once && small_mode == 0) {             // costliest, cheapest, second costliest, second cheapest, ...
+    if (all_start_at_once) {             // costliest, cheapest, second costliest, second cheapest, ...
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tmp[i] = order[i];
         __syncthreads();
@@ -508,8 +460,8 @@ __global__ void __launch_bounds__(1024) dsrt_tile_reorder_kernel(const uint32_t*
     }
 }
 
-hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, int small_mode, hipStream_t stream) {
-    hipLaunchKernelGGL(dsrt_tile_reorder_kernel, dim3(1), dim3(1024), 0, stream, work, order, tmp, sched, small_mode);
+hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_tile_reorder_kernel, dim3(1), dim3(1024), 0, stream, work, order, tmp, sched);
     return hipGetLastError();
 }
 
@@ -575,12 +527,6 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
     }
     return hipGetLastError();
 }
-
-hipError_t launch_poolcost(const RenderArgs& a, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(dsrt_poolcost_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
-    return hipGetLastError();
-}
-int poolcost_words() { return kPoolWords; }
 
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(dsrt_probe_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);

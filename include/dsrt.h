@@ -175,21 +175,17 @@ typedef struct DsrtRenderDesc {
                                        shadow-ray early-out, whose counters equal the reference traversal's exactly */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
-    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, pre-pass flags: low two
-                                       bits 1 = natural tile order and no empty-tile culling, 2 = costliest-first order but no culling;
-                                       +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe launch to refine the order;
-                                       +16 = rng_mode 1: idle lanes do not take over samples of busy lanes;
-                                       +32 = probe orders tiles by the sum of their pixels' cost instead of the costliest pixel;
-                                       +64 = 8 probe samples instead of 4; +128 = the state-move cost experiment;
-                                       bits 8-19 = rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass);
-                                       bits 20-21 = probe order when every heavy pixel starts at once: 0 = dealt costliest / cheapest
-                                       alternately, 1 = coverage order kept, 2 = plain costliest first; +(1 << 22) = probe one pixel in four;
-                                       bits 23-25 = rng_mode 0 issue priority: 0 = waves holding a heavy tile's pixel run above the rest,
-                                       7 = off, 2-6 = finer grades (experiments); bits 28-29 = rng_mode 1: least samples per work item of a
-                                       background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512; bit 31 = background pixels one item each;
-                                       bit 27 = counting build of rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as
-                                       bit patterns, 100 MHz ticks, instead of the colour (tools/chain_timeline.py)}
-                                       (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel); none of them changes a pixel */
+    int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, flags}.  None of them
+                                       changes a pixel.  Flags: low two bits 1 = natural tile order and no empty-tile culling, 2 = costliest-
+                                       first order but no culling; +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe
+                                       launch to refine the order; +16 = rng_mode 1: idle lanes do not take over samples of busy lanes;
+                                       +64 = 8 probe samples instead of 4; bits 8-19 = rng_mode 1: slices per heavy pixel (0 = chosen by
+                                       the pre-pass); bits 23-25 = rng_mode 0 issue priority: 0 = waves holding a heavy tile's pixel run
+                                       above the rest, 7 = off, 2-6 and bit 26 = finer grades (experiments); bit 27 = counting build of
+                                       rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as bit patterns, 100 MHz
+                                       ticks, instead of the colour (tools/chain_timeline.py); bits 28-29 = rng_mode 1: least samples per
+                                       work item of a background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512; bit 31 = background pixels one
+                                       item each (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel) */
 } DsrtRenderDesc;
 
 typedef struct DsrtStats {
