@@ -220,6 +220,8 @@ def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, 
     frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
     mine = sequence.frame_assignment(frames, rank, world, args.split)
     shard = (rank, world, shard_mod.gather_to_root) if (world > 1 and args.split == "tiles") else None
+    if args.batch > 0 and shard is None:
+        return run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
     pipe = sequence.FramePipeline(d, ctx, W, H, spp, depth, inflight=args.inflight, rng_mode=args.rng_mode, device=dev, shard=shard, tune=(0, 0, 0, args.tune3))
 
     def go(ids):
@@ -257,6 +259,61 @@ def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, 
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}), flush=True)
 
 
+def run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, depth, rank, world, dev, n_tris, mesh_name):
+    """configs[4] through dsrt_render_batch: this rank's poses in launches of --batch frames each, nearest (costliest) poses first; two
+    contexts on two streams take the launches in turn, so one launch's last chains run under the next launch's bulk and its images go to
+    pinned host memory meanwhile."""
+    import torch
+    import torch.distributed as dist
+    B = args.batch
+    ids = sorted(mine, reverse=True)
+    groups = [ids[k:k + B] for k in range(0, len(ids), B)]
+    cams = {i: frame_scene(i) for i in ids}
+    ctxs = [ctx, ctx.clone()]
+    with torch.cuda.device(dev):
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros(B * W * H * 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+    host = [torch.empty(B * W * H * 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    desc = d.make_desc(W, H, spp, depth, rng_mode=args.rng_mode, tune=(0, 0, 0, args.tune3))
+
+    def go(gs):
+        for k, g in enumerate(gs):
+            slot = k % 2
+            with torch.cuda.stream(streams[slot]):
+                ctxs[slot].render_batch(desc, [cams[i][1] for i in g], [tuple(cams[i][0].sun_dir_model) for i in g], bufs[slot].data_ptr(),
+                                        stream=streams[slot].cuda_stream)
+                n = len(g) * W * H * 3
+                host[slot][:n].copy_(bufs[slot][:n], non_blocking=True)
+        for st in streams:
+            st.synchronize()
+
+    go([groups[-1][:2]] * 2 if groups else [])                        # warm-up of both slots (not timed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    go(groups)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctxs[1].close()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/s (pose sequence, 1920x1080, scene resident, frames rendered as batch launches, images copied to pinned host memory)",
+            "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": 4,
+            "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
+            "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
+                                   f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode, "bvh": args.bvh,
+                       "frames_per_launch": B, "launches_per_rank": len(groups), "split": "frames" if world > 1 else "single GPU",
+                       "parallelism": "poses dealt round-robin to ranks, no data-path collective" if world > 1 else "one GPU"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,6 +339,7 @@ def main():
     ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
+    ap.add_argument("--batch", type=int, default=0, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
     ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

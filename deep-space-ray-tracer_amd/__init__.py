@@ -249,6 +249,17 @@ class Context:
         _check(rc, "dsrt_render")
         return st
 
+    def render_batch(self, desc, cameras, sun_dirs, d_rgb8_ptr, d_f32_ptr=None, stream=None, want_stats=False):
+        """dsrt_render_batch: len(cameras) views of the resident scene as one launch; the images land one after another in d_rgb8."""
+        n = len(cameras)
+        cams = (GPUCamera * n)(*cameras)
+        suns = (C.c_float * (3 * n))(*[float(v) for s in sun_dirs for v in s])
+        st = DsrtStats() if want_stats else None
+        rc = lib.dsrt_render_batch(self._h, C.byref(desc), n, cams, suns, C.c_void_p(d_rgb8_ptr), C.c_void_p(d_f32_ptr) if d_f32_ptr else None,
+                                   C.c_void_p(stream) if stream else None, C.byref(st) if st is not None else None)
+        _check(rc, "dsrt_render_batch")
+        return st
+
     def deinterleave(self, desc, d_gathered_ptr, d_image_ptr, stream=None):
         _check(lib.dsrt_deinterleave_tiles(self._h, C.byref(desc), C.c_void_p(d_gathered_ptr), C.c_void_p(d_image_ptr),
                                            C.c_void_p(stream) if stream else None), "dsrt_deinterleave_tiles")

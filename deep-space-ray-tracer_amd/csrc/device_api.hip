@@ -24,6 +24,9 @@
 namespace dsrt {
 hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream);
+hipError_t launch_batch_table(BatchFrame* table, const uint32_t* sched, uint32_t sched_stride, uint32_t frames, uint32_t tt, int rng_mode, int spp, int light_chunk_len,
+                              uint32_t* total_items, hipStream_t stream);
 hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n, uint32_t* ours, uint32_t* theirs, hipStream_t stream);
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
@@ -255,6 +258,8 @@ struct DsrtContext {
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp, probe_queue;
+    DevBuf<BatchFrame> batch_table;  // dsrt_render_batch: one entry per frame
+    std::vector<BatchFrame> batch_host;
     DevBuf<unsigned long long> accum_fixed;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t done = nullptr;      // recorded behind every render: the next render on ANY stream waits for it (queue words, spill strip,
@@ -408,7 +413,10 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
     return DSRT_OK;
 }
 
-int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream_v, DsrtStats* stats) {
+// What a batch launch adds to a render: the frames' cameras and sun directions (the context's own camera is not used).
+struct BatchInput { int frames; const GPUCamera* cameras; const DsrtF3* sun_dirs; };
+
+static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream_v, DsrtStats* stats, const BatchInput* batch) {
     if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
     if (!ctx->scene || !ctx->scene->valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
     if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
@@ -445,7 +453,16 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     f.total_items = (uint32_t)t.mine * (uint32_t)(t.tile * t.tile);
     f.compact_output = desc->shard_count > 1 ? 1 : 0;
     f.chunks = 1; f.chunk_len = f.spp; f.light_chunk_len = f.spp;
-    const size_t out_pixels = desc->shard_count > 1 ? (size_t)t.padded * t.tile * t.tile : (size_t)desc->width * desc->height;
+    const int frames = batch ? batch->frames : 1;
+    if (batch) {
+        if (frames < 1 || !batch->cameras || !batch->sun_dirs) { set_error("dsrt_render_batch: no frames"); return DSRT_ERR_INVALID; }
+        if (desc->shard_count > 1 || desc->collect_counters || desc->checked) { set_error("dsrt_render_batch renders whole frames with the production kernel only"); return DSRT_ERR_INVALID; }
+        // 32-bit output indices and work-item numbers: frames x pixels (x 8 sample slices in rng_mode 1) stay below 2^32
+        if ((unsigned long long)frames * (unsigned long long)desc->width * desc->height * (desc->rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) {
+            set_error("dsrt_render_batch: too many pixels in one batch (split the sequence)"); return DSRT_ERR_INVALID;
+        }
+    }
+    const size_t out_pixels = (desc->shard_count > 1 ? (size_t)t.padded * t.tile * t.tile : (size_t)desc->width * desc->height) * (size_t)frames;
     if (desc->rng_mode == 1) {
         // a pixel's samples are independent streams: pixels of tiles that see geometry are split into 8 work items.  More slices cost
         // more in half-empty advance passes than their shorter tail saves; fewer leave whole waves without work at the end of a small
@@ -489,9 +506,10 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     const int threads_per_block = 64 * kernel_waves_per_block();
     const int resident_blocks = ctx->num_cus * 4;                         // 4 waves per SIMD = 4 workgroups of 4 waves per CU (render_kernel.hip)
     int blocks = resident_blocks;                                         // persistent: exactly the resident set
+    if ((desc->tune[3] >> 20) & 7) blocks = std::max(1, resident_blocks >> ((desc->tune[3] >> 20) & 7));     // experiment: a fraction of it (frames that overlap)
     {
         const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
-        if (needed < blocks) blocks = (int)(needed > 0 ? needed : 1);
+        if (needed < blocks && !batch) blocks = (int)(needed > 0 ? needed : 1);
     }
     const int spill_entries = sc.view.stack_need > K ? sc.view.stack_need - K : 0;
     const size_t lanes = (size_t)blocks * threads_per_block;
@@ -519,11 +537,39 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     // see dsrt_tile_cost_kernel).  tune[3] == 1 switches both off, == 2 keeps the order but culls nothing; counting builds never
     // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
     // tiles that see geometry and the number of tiles in the order.
+    const size_t pre_stride = (size_t)t.mine + 64;          // per frame: tile costs / order, then the sched words
     for (DevBuf<uint32_t>* b : {&ctx->tile_cost, &ctx->tile_order, &ctx->tile_work, &ctx->tile_tmp}) {      // each by its own size: a failed
-        if (b->n < (size_t)t.mine + 64) { int rc = b->alloc((size_t)t.mine + 64); if (rc) return rc; }      // allocation leaves no stale sibling
+        const size_t want = (b == &ctx->tile_cost || b == &ctx->tile_order) ? pre_stride * (size_t)frames : pre_stride;
+        if (b->n < want) { int rc = b->alloc(want); if (rc) return rc; }                                    // allocation leaves no stale sibling
     }
     uint32_t* sched = ctx->tile_cost.p + t.mine + 32;       // {tiles that see geometry, tiles in the order, heavy lanes per wave}
     a.sched = sched;
+    if (batch) {
+        // Batch: every frame's pre-pass (exact culling + coverage order; no probe: the frames' chains overlap whatever their order), its
+        // results left pre_stride apart; then one small kernel turns the counts into the table the render kernel looks work items up in.
+        // Slices stay at the host's 8 (resident_lanes = 0: the pool is never short of heavy pixels).
+        const bool cull = (desc->tune[3] & 3) == 0;
+        HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));                          // culled pixels are never written
+        if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
+        if (ctx->batch_table.n < (size_t)frames) { int rc = ctx->batch_table.alloc((size_t)frames); if (rc) return rc; }
+        ctx->batch_host.assign((size_t)frames, BatchFrame{});
+        for (int i = 0; i < frames; ++i) {
+            const GPUCamera& bc = batch->cameras[i];
+            BatchFrame& e = ctx->batch_host[(size_t)i];
+            const float cam12[12] = {bc.origin.x, bc.origin.y, bc.origin.z, bc.lower_left_corner.x, bc.lower_left_corner.y, bc.lower_left_corner.z,
+                                     bc.horizontal.x, bc.horizontal.y, bc.horizontal.z, bc.vertical.x, bc.vertical.y, bc.vertical.z};
+            std::memcpy(e.cam_origin, cam12, sizeof cam12);                                   // origin, llc, horizontal, vertical are contiguous
+            e.sun_dir[0] = batch->sun_dirs[i].x; e.sun_dir[1] = batch->sun_dirs[i].y; e.sun_dir[2] = batch->sun_dirs[i].z;
+            e.order_base = (uint32_t)(pre_stride * (size_t)i);
+            std::memcpy(a.frame.cam_origin, cam12, sizeof cam12);
+            HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p + pre_stride * (size_t)i, ctx->tile_order.p + pre_stride * (size_t)i,
+                                      sched + pre_stride * (size_t)i, (uint32_t)f.chunks, 0u, cull, stream));
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->batch_table.p, ctx->batch_host.data(), (size_t)frames * sizeof(BatchFrame), hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_batch_table(ctx->batch_table.p, sched, (uint32_t)pre_stride, (uint32_t)frames, (uint32_t)(t.tile * t.tile), desc->rng_mode, f.spp,
+                                   f.light_chunk_len, ctx->ctrl.p + 2, stream));
+        a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = (uint32_t)frames;
+    } else
     if ((desc->tune[3] & 3) != 1 && t.mine > 0) {
         const bool cull = (desc->tune[3] & 3) != 2 && desc->collect_counters == 0;
         if (cull) {                                             // culled pixels are never written: they are the zeros put here
@@ -538,7 +584,7 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         // long chain; tune[3] bit 3 (value 8) switches it off.
         constexpr int kProbeSpp = 4;          // x every pixel of the heavy tiles: 7 ms at 1080p, near frame.  (1, 2, 4 or 8 samples order the tiles equally well.)
         // Its work items are tiny, so the probe has 64 queue words of its own (path_machine.h, ST_FETCH): on the frame's single queue word
-        // the same launch took 27 ms.  tune[3] + (1 << 22) probes one pixel in four (round 2's first version: 4.4 ms, near frame 3 % slower).
+        // the same launch took 27 ms.
         // Only with the reference's stream: in rng_mode 1 a pixel is cut into slices and lanes share samples, so there is no long chain to start
         // early, and the coverage order alone is better (interleaved medians, near frame: 1046 -> 1037 ms, one of 8 shares 176 -> 167 ms).
         if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 64 * kProbeSpp) {
@@ -563,7 +609,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    if (batch) HIP_TRY(launch_render_batch(a, desc->rng_mode, blocks, stream));
+    else HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));
     ctx->done_valid = true;
@@ -605,6 +652,21 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
         }
     }
     return DSRT_OK;
+}
+
+int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats) {
+    return render_impl(ctx, desc, d_rgb8, d_f32, stream, stats, nullptr);
+}
+
+int dsrt_render_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz, uint8_t* d_rgb8, float* d_f32,
+                      void* stream, DsrtStats* stats) {
+    return dsrt::guarded("dsrt_render_batch", [&]() -> int {
+        if (frames < 1 || !cameras || !sun_dirs_xyz) { set_error("dsrt_render_batch: null argument"); return DSRT_ERR_INVALID; }
+        std::vector<DsrtF3> suns((size_t)frames);
+        for (int i = 0; i < frames; ++i) suns[(size_t)i] = DsrtF3{sun_dirs_xyz[3 * i], sun_dirs_xyz[3 * i + 1], sun_dirs_xyz[3 * i + 2]};
+        const BatchInput b{frames, cameras, suns.data()};
+        return render_impl(ctx, desc, d_rgb8, d_f32, stream, stats, &b);
+    });
 }
 
 int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image, void* stream) {

@@ -55,6 +55,7 @@ struct Lane {
     int sample_end = 0;                          // rng_mode 1: this work item covers samples [.., sample_end) of the pixel
     uint32_t chunk = 0;                          // rng_mode 1: which slice of the pixel's samples
     uint32_t aux = 0;                            // lane number inside the wave + helper / await bits (see above)
+    uint32_t frame = 0;                          // batch launches (dsrt_render_batch): which frame of the batch this lane's pixel belongs to
     uint32_t t0 = 0;                             // counting build: wall clock (100 MHz, low 32 bits) when this lane fetched its current work item
     F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
@@ -106,7 +107,7 @@ __device__ __forceinline__ typename RngOf<RNGMODE>::type make_rng(Lane& ln, cons
     }
 }
 
-template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
+template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
 __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, uint32_t* c, uint32_t& flags) {
     const DeviceScene& S = args.scene;
     const FrameParams& P = args.frame;
@@ -274,7 +275,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     bool need_shadow = false;
                     F3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0);
                     if (P.sun_enabled) {
-                        const F3 Ldir = normalize(mk(-P.sun_dir[0], -P.sun_dir[1], -P.sun_dir[2]));
+                        const float* sun = BATCH ? args.batch[ln.frame].sun_dir : P.sun_dir;
+                        const F3 Ldir = normalize(mk(-sun[0], -sun[1], -sun[2]));
                         const float cos_t = fmaxf(0.0f, dot(hn, Ldir));
                         if (cos_t > 0.0f) {
                             sh_o = hp + (hn * 1e-3f);
@@ -446,9 +448,24 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // The probe visits the heavy tiles only, every pixel (a tile's place is decided by its costliest pixel, so a sample of its
         // pixels misses it: all against one in four, near frame 1157 -> 1126 ms, spread 1141-1162 -> 1114-1131).
         const uint32_t tt = (uint32_t)(P.tile * P.tile);
-        const uint32_t n_heavy = args.sched[0], n_live = PROBE ? args.sched[0] : args.sched[1], spread = args.sched[2];
-        const uint32_t per_pixel = RNGMODE == 1 ? args.sched[3] : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
-        const int chunk_len = RNGMODE == 1 ? (int)args.sched[4] : spp;
+        // Batch launch (dsrt_render_batch: many frames of one scene as ONE pool of work): a single queue runs through the frames in order,
+        // each frame's heavy tiles first, then its light ones; the item number says which frame (its table entry carries that frame's
+        // camera, sun, tile order and the counts its pre-pass found).  A lane that finishes a pixel of frame f simply goes on with whatever
+        // comes next, so the serial chains of one frame run under the bulk of the following ones and no lane waits for a frame to end.
+        uint32_t bitem = 0;
+        const BatchFrame* bf = nullptr;
+        if constexpr (BATCH) {
+            bitem = atomicAdd(args.queue, 1u);
+            uint32_t lo = 0, hi = args.batch_frames - 1u;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bitem < args.batch[mid].item_end) hi = mid; else lo = mid + 1u; }
+            bf = args.batch + lo;
+            ln.frame = lo;
+            if (bitem >= args.batch[args.batch_frames - 1u].item_end) bitem = 0xFFFFFFFFu;     // past the last frame: no work left
+            else if (lo) bitem -= args.batch[lo - 1u].item_end;
+        }
+        const uint32_t n_heavy = BATCH ? bf->n_heavy : args.sched[0], n_live = BATCH ? bf->n_live : (PROBE ? args.sched[0] : args.sched[1]), spread = BATCH ? 64u : args.sched[2];
+        const uint32_t per_pixel = RNGMODE == 1 ? (BATCH ? bf->slices : args.sched[3]) : 1u;          // slices per heavy pixel and their length: decided by the pre-pass
+        const int chunk_len = RNGMODE == 1 ? (BATCH ? (int)bf->chunk_len : (int)args.sched[4]) : spp;
         // Pixels of the light tiles are cut into items of P.light_chunk_len samples (host: dsrt_render).  They were one item each until the
         // queue marks of the counting build -- DsrtStats.heavy_queue_empty_ms -- showed what that did: the light queue is served last, and
         // a 1000-sample item of cheap samples is a longer job than a 125-sample item of dear ones, so the biggest jobs came last.
@@ -463,6 +480,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             // wave number, each handing out the items congruent to its number modulo 64: the atomics of different waves no longer queue up.
             const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63u;
             item = shard + 64u * atomicAdd(args.probe_queue + shard * 16u, 1u);
+        } else if constexpr (BATCH) {
+            heavy = bitem < heavy_items;
+            item = bitem == 0xFFFFFFFFu ? bitem : (heavy ? bitem : bitem - heavy_items);
         } else {
             if (heavy) item = atomicAdd(args.queue, 1u); else item = atomicAdd(args.queue_light, 1u);   // (uniform address per branch:
             if (item >= (heavy ? heavy_items : light_items)) {                                          //  one atomic per wave)
@@ -492,7 +512,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             state = ST_DONE;
         } else {
             const uint32_t within = item % tt;
-            const uint32_t k = P.tile_order ? P.tile_order[item / tt] : item / tt;
+            const uint32_t* order = BATCH ? args.batch_order + bf->order_base : P.tile_order;
+            const uint32_t k = order ? order[item / tt] : item / tt;
             const uint32_t g = k * (uint32_t)P.shard_count + (uint32_t)P.shard_rank;
             const uint32_t tx = g % (uint32_t)P.tiles_x, ty = g / (uint32_t)P.tiles_x;
             const uint32_t per_row = (uint32_t)P.tile >> 3;
@@ -504,6 +525,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                 px = x;
                 ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
                 out_index = P.compact_output ? (k * (uint32_t)(P.tile * P.tile) + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
+                if constexpr (BATCH) out_index += ln.frame * (uint32_t)(W * H);          // the batch's images lie one after another
                 accum = mk(0, 0, 0);
                 if (COUNT) ln.t0 = (uint32_t)wall_clock64();
                 if constexpr (RNGMODE == 0) {
@@ -544,6 +566,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                         ln.pend[1 * kPendStride] = __uint_as_float(out_index);
                         ln.pend[2 * kPendStride] = __uint_as_float((uint32_t)mid);
                         ln.pend[3 * kPendStride] = __uint_as_float((uint32_t)ln.sample_end);
+                        if constexpr (BATCH) ln.pend[4 * kPendStride] = __uint_as_float(ln.frame);
                         ln.sample_end = mid;
                     }
                 }
@@ -559,6 +582,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                         out_index = __float_as_uint(theirs[1 * kPendStride]);
                         sample = (int)__float_as_uint(theirs[2 * kPendStride]);
                         ln.sample_end = (int)__float_as_uint(theirs[3 * kPendStride]);
+                        if constexpr (BATCH) ln.frame = __float_as_uint(theirs[4 * kPendStride]);
                         accum = mk(0, 0, 0);                       // bit pattern 0: integer sums start at zero
                         restream();
                         state = ST_GEN;
@@ -573,7 +597,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             float jy = ((float)sample + rand01(rng)) / (float)spp;
             float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
             float v = ((float)ky + jy) / (float)(H - 1);
-            const F3 cam_o = ld3(P.cam_origin), cam_llc = ld3(P.cam_llc), cam_h = ld3(P.cam_horizontal), cam_v = ld3(P.cam_vertical);
+            const float* cam = BATCH ? args.batch[ln.frame].cam_origin : P.cam_origin;       // origin, lower-left corner, horizontal, vertical: 12 floats in a row
+            const F3 cam_o = ld3(cam), cam_llc = ld3(cam + 3), cam_h = ld3(cam + 6), cam_v = ld3(cam + 9);
             ro = cam_o;
             rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
             depth = 0;

@@ -38,7 +38,7 @@ constexpr int kWavesPerBlock = 4;
 #define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -79,7 +79,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
             if (state < ST_TRAV_CLOSEST || state == ST_DONE) {
-                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE>(ln, args, c, flags);
+                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH>(ln, args, c, flags);
             }
         }
 
@@ -260,6 +260,29 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
     render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false>(args);
+}
+
+// Batch launch: many frames of one scene as one pool of work (path_machine.h, ST_FETCH).
+template <int RNGMODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_batch_kernel(const RenderArgs args) {
+    render_body<8, false, false, true, RNGMODE, false, true>(args);
+}
+
+// Fills the count fields of the batch table from the sched words every frame's pre-pass wrote (sched_stride apart), and the running item total.
+__global__ void dsrt_batch_table_kernel(BatchFrame* __restrict__ table, const uint32_t* __restrict__ sched, uint32_t sched_stride, uint32_t frames,
+                                        uint32_t tt, int rng_mode, int spp, int light_chunk_len, uint32_t* __restrict__ total_items) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long acc = 0;
+    for (uint32_t f = 0; f < frames; ++f) {
+        const uint32_t* s = sched + (size_t)f * sched_stride;
+        BatchFrame& e = table[f];
+        e.n_heavy = s[0]; e.n_live = s[1];
+        e.slices = rng_mode == 1 ? s[3] : 1u; e.chunk_len = rng_mode == 1 ? s[4] : (uint32_t)spp;
+        const uint32_t light_slices = rng_mode == 1 ? (uint32_t)((spp + light_chunk_len - 1) / light_chunk_len) : 1u;
+        acc += (unsigned long long)e.n_heavy * tt * e.slices + (unsigned long long)(e.n_live - e.n_heavy) * tt * light_slices;
+        e.item_end = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;           // (the host bounds frames x pixels x 64 below 2^32)
+    }
+    *total_items = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;
 }
 
 // The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
@@ -525,6 +548,19 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
     } else {
         hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE>), grid, block, 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream) {
+    if (rng_mode == 0) hipLaunchKernelGGL(dsrt_render_batch_kernel<0>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+    else if (rng_mode == 1) hipLaunchKernelGGL(dsrt_render_batch_kernel<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_table(BatchFrame* table, const uint32_t* sched, uint32_t sched_stride, uint32_t frames, uint32_t tt, int rng_mode, int spp, int light_chunk_len,
+                              uint32_t* total_items, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_batch_table_kernel, dim3(1), dim3(64), 0, stream, table, sched, sched_stride, frames, tt, rng_mode, spp, light_chunk_len, total_items);
     return hipGetLastError();
 }
 

@@ -228,6 +228,23 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
  */
 int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats);
 
+/*
+ * Render `frames` views of the resident scene as ONE launch: the reference's frame loop (src/main.cpp:310-431) with the scene kept and
+ * only camera and sun changing, but with all frames' pixels in a single pool of work.  In rng_mode 0 a pixel is a serial chain of spp
+ * samples and a frame rendered alone ends in a tail of a few such chains on an otherwise empty chip; here a lane that finishes a pixel
+ * of frame f goes straight on to frame f + 1, so the chains of one frame run under the bulk of the next ones.  Every frame's image is the
+ * image dsrt_render gives for that camera and sun, byte for byte (rng_mode 0: the reference's; rng_mode 1: seed-determined).
+ *   cameras      : `frames` cameras (dsrt_camera_look_at / dsrt_pose_frame_camera), HOST array
+ *   sun_dirs_xyz : 3 * frames floats, HOST array (radiance and the enabled flag are the context's, dsrt_scene_set_camera_sun)
+ *   d_rgb8       : DEVICE buffer, frames * width*height*3 bytes: the images one after another, each in dsrt_render's layout
+ *   d_f32        : optional DEVICE buffer, frames * width*height*3 floats
+ * Whole frames only (shard_count <= 1), production kernel only (no counters, not `checked`); frames * width * height (x 16 in rng_mode 1)
+ * must stay below 2^32 -- split a longer sequence into several calls.  Asynchronous on `stream` unless `stats` is given
+ * (kernel_ms then covers the one launch; the per-frame pre-passes before it are not included).
+ */
+int dsrt_render_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz,
+                      uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats);
+
 /* Root rank, after a gather: tile-major shards [shard][tile][tile*tile*3] -> image-order rgb8. */
 int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image,
                             void* stream);

@@ -605,6 +605,46 @@ def test_sequence_flow_frames_in_flight_match_the_oracle(dsrt, gpu_ctx, oracle, 
     multi.close()
 
 
+def test_batch_launch_gives_every_frame_its_own_image(dsrt, gpu_ctx, oracle, tmp_path):
+    """dsrt_render_batch: the frames of a sequence as ONE launch -- a single queue that runs through the frames, a lane going from a pixel of
+    one frame straight to the next -- over 7 poses from the far end to the near end, plus a ragged size.  rng_mode 0: every frame is the
+    oracle's image byte for byte (uint8 and float); rng_mode 1: every frame is what dsrt_render gives for that camera alone.  At 64 and 300
+    samples, so that with the larger count a pixel is a chain long enough for several frames' work to be in flight under it."""
+    import torch
+    _, hs, poses = _station_scene(dsrt, tmp_path, 20000)
+    depth = 50
+    frames = [0, 30, 70, 90, 96, 97, 98]
+    for W, H, spp in ((320, 180, 64), (150, 85, 300)):
+        def frame(i):
+            fr = dsrt.pose_to_frame(poses[i])
+            return dsrt.frame_camera(fr, 40.0, W, H, spp, depth), tuple(fr.sun_dir_model)
+        cams, suns = zip(*[frame(i) for i in frames])
+        gpu_ctx.upload(hs.view(cams[0], suns[0]))
+        n = len(frames)
+        rgb = torch.zeros(n * H * W * 3, dtype=torch.uint8, device="cuda")
+        f32 = torch.zeros(n * H * W * 3, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        st = gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth), list(cams), list(suns), rgb.data_ptr(), f32.data_ptr(), stream=stream, want_stats=True)
+        assert st.kernel_ms > 0 and st.device_flags == 0
+        got = rgb.cpu().numpy().reshape(n, H, W, 3)
+        got32 = f32.cpu().numpy().reshape(n, H, W, 3)
+        for k, i in enumerate(frames):
+            want, want32, _ = oracle.render(hs.view(cams[k], suns[k]), W, H)
+            assert np.array_equal(got[k], want), f"{W}x{H}@{spp} frame {i}: {(got[k] != want).any(axis=2).sum()} pixels differ"
+            assert np.array_equal(got32[k].view(np.uint32), want32.view(np.uint32)), i
+        gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, rng_mode=1), list(cams), list(suns), rgb.data_ptr(), stream=stream, want_stats=True)
+        got1 = rgb.cpu().numpy().reshape(n, H, W, 3)
+        for k, i in enumerate(frames):
+            gpu_ctx.set_camera_sun(cams[k], suns[k])
+            alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
+            assert np.array_equal(got1[k], alone), f"rng_mode 1, frame {i}"
+    # what a batch cannot be: sharded, counted, or bigger than its 32-bit indices
+    with pytest.raises(dsrt.DsrtError):
+        gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, shard_rank=0, shard_count=2), list(cams), list(suns), rgb.data_ptr())
+    with pytest.raises(dsrt.DsrtError):
+        gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, collect_counters=1), list(cams), list(suns), rgb.data_ptr())
+
+
 def test_eight_ranks_at_the_1080p_layout(dsrt, gpu_ctx, oracle, tmp_path):
     """BASELINE.json configs[3]'s layout on one GPU: 1920x1080 in 8x8 tiles is 32,400 tiles, 4,050 per rank with 8 ranks (equal here;
     the padded case is covered at 1918x1078 -> 32,400 tiles too but ragged edges, and by the CPU layout tests).  Eight shards rendered
