@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
-    ap.add_argument("--batch", type=int, default=0, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
+    ap.add_argument("--batch", type=int, default=99, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
     ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

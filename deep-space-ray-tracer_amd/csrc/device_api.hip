@@ -34,7 +34,7 @@ hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, i
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
-                             uint32_t resident_lanes, bool cull, hipStream_t stream);
+                             uint32_t resident_lanes, bool cull, hipStream_t stream, const BatchFrame* batch = nullptr, uint32_t frames = 1, uint32_t stride = 0);
 hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream);
 hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
 }  // namespace dsrt
@@ -561,11 +561,10 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             std::memcpy(e.cam_origin, cam12, sizeof cam12);                                   // origin, llc, horizontal, vertical are contiguous
             e.sun_dir[0] = batch->sun_dirs[i].x; e.sun_dir[1] = batch->sun_dirs[i].y; e.sun_dir[2] = batch->sun_dirs[i].z;
             e.order_base = (uint32_t)(pre_stride * (size_t)i);
-            std::memcpy(a.frame.cam_origin, cam12, sizeof cam12);
-            HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p + pre_stride * (size_t)i, ctx->tile_order.p + pre_stride * (size_t)i,
-                                      sched + pre_stride * (size_t)i, (uint32_t)f.chunks, 0u, cull, stream));
         }
         HIP_TRY(hipMemcpyAsync(ctx->batch_table.p, ctx->batch_host.data(), (size_t)frames * sizeof(BatchFrame), hipMemcpyHostToDevice, stream));
+        HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, sched, (uint32_t)f.chunks, 0u, cull, stream,
+                                  ctx->batch_table.p, (uint32_t)frames, (uint32_t)pre_stride));
         HIP_TRY(launch_batch_table(ctx->batch_table.p, sched, (uint32_t)pre_stride, (uint32_t)frames, (uint32_t)(t.tile * t.tile), desc->rng_mode, f.spp,
                                    f.light_chunk_len, ctx->ctrl.p + 2, stream));
         a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = (uint32_t)frames;

@@ -9,8 +9,9 @@
 //     a small kernel restores image order there, and the image is copied to the caller's host buffer.
 //   * dsrt_multi_render_sequence   MANY frames of one scene (the pose file): frame i goes WHOLE to rank i mod N -- no collective
 //     at all, the natural shard for a sequence, and the only one that scales in rng_mode 0, where a pixel is a serial chain of spp
-//     samples whatever the number of GPUs.  Each rank keeps `frames_in_flight` frames going on separate
-//     streams (clones of its context: the scene is resident once per GPU) and copies finished images to pinned host memory.
+//     samples whatever the number of GPUs.  Each rank renders its frames in batch launches (dsrt_render_batch:
+//     up to 32 frames as one pool of work), its slots (clones of its context: the scene is resident once per GPU) taking the launches
+//     in turn, and copies finished images to pinned host memory.
 //
 // All launches are asynchronous, so one host thread keeps N devices busy.  torch is not involved; torch.distributed (bench.py)
 // is the one-process-per-GPU alternative over the same kernels and the same shard layout.
@@ -21,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <set>
@@ -271,35 +273,66 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
         DsrtRenderDesc d = *desc_in;
         d.shard_count = 0; d.shard_rank = 0;                        // whole frames
         const size_t image_bytes = (size_t)d.width * d.height * 3;
+        // Rank r renders frames r, r + N, ... in batch launches (dsrt_render_batch: the frames of a launch are one pool of work, so the serial
+        // chains of one frame run under the bulk of the others), nearest poses first when the caller's order ends near, as the pose file's
+        // does; at most kGroup frames per launch, the rank's slots taking the launches in turn so that one launch's images travel to the
+        // host while the next one renders.
+        constexpr int kGroup = 32;
         int rc;
+        std::vector<std::vector<int>> mine((size_t)n);
+        for (int i = n_frames - 1; i >= 0; --i) mine[(size_t)(i % n)].push_back(i);          // last (nearest) first
+        size_t per_launch = 1;
+        for (const auto& v : mine) per_launch = std::max(per_launch, std::min(v.size(), (size_t)kGroup));
+        // 32-bit work-item numbers inside a launch (include/dsrt.h): fewer frames per launch for very large images
+        while (per_launch > 1 && (unsigned long long)per_launch * d.width * d.height * (d.rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;
         for (Rank& k : m->ranks) {
             HIP_TRY(hipSetDevice(k.device));
-            for (Slot& s : k.slots) { if ((rc = ensure_slot_images(s, image_bytes))) return rc; s.frame = -1; }
+            for (Slot& s : k.slots) { if ((rc = ensure_slot_images(s, image_bytes * per_launch))) return rc; s.frame = -1; }
         }
         const auto t0 = std::chrono::steady_clock::now();
-        // Before a slot is re-used its previous image is handed over -- the only reason for the host to wait on a slot.  With nobody
-        // to hand it to, stream order alone protects the slot's buffers, and not waiting keeps every slot busy while one long near
-        // frame is still rendering.
-        auto retire = [&](Slot& s, bool final_pass) -> int {
-            const bool wanted = s.frame >= 0 && h_images && h_images[s.frame];
-            if (wanted || final_pass) HIP_TRY(hipStreamSynchronize(s.stream));
-            if (wanted) std::memcpy(h_images[s.frame], s.h_pinned, image_bytes);
-            s.frame = -1;
+        std::vector<std::vector<std::vector<int>>> held((size_t)n);                              // per rank, per slot: the frames whose images the slot holds
+        for (int r = 0; r < n; ++r) held[(size_t)r].resize(m->ranks[(size_t)r].slots.size());
+        // Before a slot is re-used its images are handed over -- the only reason for the host to wait on a slot.
+        auto retire = [&](int r, size_t si) -> int {
+            Slot& s = m->ranks[(size_t)r].slots[si];
+            std::vector<int>& frames = held[(size_t)r][si];
+            if (frames.empty()) return DSRT_OK;
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            for (size_t q = 0; q < frames.size(); ++q)
+                if (h_images && h_images[frames[q]]) std::memcpy(h_images[frames[q]], s.h_pinned + q * image_bytes, image_bytes);
+            frames.clear();
             return DSRT_OK;
         };
-        for (int i = 0; i < n_frames; ++i) {
-            Rank& k = m->ranks[(size_t)(i % n)];                    // frame i -> rank i mod N, slot (i / N) mod K
-            Slot& s = k.slots[(size_t)((i / n) % (int)k.slots.size())];
-            HIP_TRY(hipSetDevice(k.device));
-            if ((rc = retire(s, false))) return rc;
-            if ((rc = dsrt_scene_set_camera_sun(s.ctx, &cams[i], sun_dirs + 3 * (size_t)i))) return rc;
-            if ((rc = dsrt_render(s.ctx, &d, s.d_image, nullptr, s.stream, nullptr))) return rc;
-            HIP_TRY(hipMemcpyAsync(s.h_pinned, s.d_image, image_bytes, hipMemcpyDeviceToHost, s.stream));
-            s.frame = i;
+        std::vector<size_t> next((size_t)n, 0), turn((size_t)n, 0);
+        std::vector<GPUCamera> gcams;
+        std::vector<float> gsuns;
+        for (bool any = true; any;) {                                                             // one launch per rank per round: all devices stay fed
+            any = false;
+            for (int r = 0; r < n; ++r) {
+                const std::vector<int>& v = mine[(size_t)r];
+                if (next[(size_t)r] >= v.size()) continue;
+                any = true;
+                Rank& k = m->ranks[(size_t)r];
+                const size_t si = turn[(size_t)r]++ % k.slots.size();
+                Slot& s = k.slots[si];
+                HIP_TRY(hipSetDevice(k.device));
+                if ((rc = retire(r, si))) return rc;
+                const size_t count = std::min(per_launch, v.size() - next[(size_t)r]);
+                gcams.clear(); gsuns.clear();
+                for (size_t q = 0; q < count; ++q) {
+                    const int fi = v[next[(size_t)r] + q];
+                    gcams.push_back(cams[fi]);
+                    gsuns.insert(gsuns.end(), sun_dirs + 3 * (size_t)fi, sun_dirs + 3 * (size_t)fi + 3);
+                    held[(size_t)r][si].push_back(fi);
+                }
+                next[(size_t)r] += count;
+                if ((rc = dsrt_render_batch(s.ctx, &d, (int)count, gcams.data(), gsuns.data(), s.d_image, nullptr, s.stream, nullptr))) return rc;
+                HIP_TRY(hipMemcpyAsync(s.h_pinned, s.d_image, image_bytes * count, hipMemcpyDeviceToHost, s.stream));
+            }
         }
-        for (Rank& k : m->ranks) {
-            HIP_TRY(hipSetDevice(k.device));
-            for (Slot& s : k.slots) if ((rc = retire(s, true))) return rc;
+        for (int r = 0; r < n; ++r) {
+            HIP_TRY(hipSetDevice(m->ranks[(size_t)r].device));
+            for (size_t si = 0; si < m->ranks[(size_t)r].slots.size(); ++si) if ((rc = retire(r, si))) return rc;
         }
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return DSRT_OK;

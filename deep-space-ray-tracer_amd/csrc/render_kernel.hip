@@ -341,7 +341,15 @@ __device__ bool block_footprint_misses_root(const DeviceScene& S, const FramePar
     return false;
 }
 
-__global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S, const FrameParams P, uint32_t* __restrict__ cost, int cull) {
+// (batch launches: blockIdx.y is the frame; its camera comes from the batch table and its cost words lie `stride` further on)
+__global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S, const FrameParams P0, uint32_t* __restrict__ cost, int cull,
+                                                             const BatchFrame* __restrict__ batch, uint32_t stride) {
+    FrameParams P = P0;
+    if (batch) {
+        const float* cam = batch[blockIdx.y].cam_origin;
+        for (int a = 0; a < 3; ++a) { P.cam_origin[a] = cam[a]; P.cam_llc[a] = cam[3 + a]; P.cam_horizontal[a] = cam[6 + a]; P.cam_vertical[a] = cam[9 + a]; }
+        cost += (size_t)blockIdx.y * stride;
+    }
     const uint32_t blocks_per_tile = (uint32_t)((P.tile >> 3) * (P.tile >> 3));
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -409,8 +417,10 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
 }
 
 // One block: counting sort of the shard's live tiles by cost, costliest first (65 bins; order inside a bin does not matter).
+// (batch launches: one block per frame, the frames' arrays `stride` apart)
 __global__ void __launch_bounds__(1024) dsrt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n, int tile,
-                                                               uint32_t* __restrict__ sched, uint32_t items_per_pixel, uint32_t resident_lanes, int spp) {
+                                                               uint32_t* __restrict__ sched, uint32_t items_per_pixel, uint32_t resident_lanes, int spp, uint32_t stride) {
+    cost += (size_t)blockIdx.x * stride; order += (size_t)blockIdx.x * stride; sched += (size_t)blockIdx.x * stride;
     __shared__ uint32_t bins[65], cursor[65];
     const uint32_t full = (uint32_t)(tile * tile);
     for (int b = threadIdx.x; b < 65; b += blockDim.x) bins[b] = 0;
@@ -489,12 +499,14 @@ hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* 
 }
 
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
-                             uint32_t resident_lanes, bool cull, hipStream_t stream) {
+                             uint32_t resident_lanes, bool cull, hipStream_t stream, const BatchFrame* batch = nullptr, uint32_t frames = 1, uint32_t stride = 0) {
     const uint32_t waves = (uint32_t)P.local_tiles * (uint32_t)((P.tile >> 3) * (P.tile >> 3));
-    hipError_t e = hipMemsetAsync(cost, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, S, P, cost, cull ? 1 : 0);
-    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, sched, items_per_pixel, resident_lanes, P.spp);
+    for (uint32_t f = 0; f < frames; ++f) {                           // (the cost words only: the arrays carry the sched words behind them)
+        hipError_t e = hipMemsetAsync(cost + (size_t)f * stride, 0, (size_t)P.local_tiles * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(dsrt_tile_cost_kernel, dim3((waves + 3) / 4, frames), dim3(256), 0, stream, S, P, cost, cull ? 1 : 0, batch, stride);
+    hipLaunchKernelGGL(dsrt_tile_order_kernel, dim3(frames), dim3(1024), 0, stream, (const uint32_t*)cost, order, P.local_tiles, P.tile, sched, items_per_pixel, resident_lanes, P.spp, stride);
     return hipGetLastError();
 }
 

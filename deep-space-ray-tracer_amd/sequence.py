@@ -7,6 +7,10 @@ queue words and scratch) and its own device + pinned host image.  Why several fr
 stream per pixel a frame ends in a tail of a few spp-sample serial chains, and the next frames' workgroups fill the CUs that
 tail leaves idle.
 
+`render_batches` goes one step further (dsrt_render_batch): the frames of a launch are ONE pool of work -- a lane that finishes a pixel of
+one frame goes straight on to the next frame -- so no chip time is lost to any frame's tail and no hardware queue limits how many frames
+overlap: the 99-pose sequence runs at 56 frames/s in rng_mode 0 on one MI355X against 40 with 16 separate launches in flight.
+
 With more than one rank (one process per GPU, torch.distributed) the job splits one of two ways:
   split="frames"  poses are dealt round-robin: rank r renders frames r, r + N, ... whole; no collective on the data path.  The
                   natural shard of a sequence, and the only one that scales in rng_mode 0 (a pixel is a serial chain however many
@@ -109,4 +113,51 @@ def render_frames(d, ctx, hs_frame, frame_ids, W, H, spp, depth, inflight=4, rng
         cam, sun = hs_frame(i)
         pipe.submit(i, cam, sun)
     pipe.close()
+    return out
+
+
+def render_batches(d, ctx, hs_frame, frame_ids, W, H, spp, depth, per_launch=32, rng_mode=0, keep=True, on_frame=None):
+    """Render `frame_ids` through dsrt_render_batch on ctx's GPU, `per_launch` frames per launch, two contexts (ctx and a clone sharing its
+    scene) taking the launches in turn so that one launch's images travel to pinned host memory while the next renders.  Frames are taken
+    in the order given (put the costliest -- nearest -- first: the job then ends on short chains).  Returns {frame id: H x W x 3 uint8}."""
+    import torch
+    ids = list(frame_ids)
+    dev = torch.device("cuda", ctx.device)
+    ctxs = [ctx, ctx.clone()]
+    with torch.cuda.device(dev):
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    n_img = W * H * 3
+    bufs = [torch.zeros(per_launch * n_img, dtype=torch.uint8, device=dev) for _ in range(2)]
+    host = [torch.empty(per_launch * n_img, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    desc = d.make_desc(W, H, spp, depth, rng_mode=rng_mode)
+    held = [[], []]
+    out = {}
+
+    def retire(slot):
+        if held[slot]:
+            streams[slot].synchronize()
+            for q, i in enumerate(held[slot]):
+                img = host[slot][q * n_img:(q + 1) * n_img]
+                if on_frame is not None:
+                    on_frame(i, img)
+                if keep:
+                    out[i] = img.numpy().reshape(H, W, 3).copy()
+            held[slot] = []
+
+    try:
+        for k in range(0, len(ids), per_launch):
+            group = ids[k:k + per_launch]
+            slot = (k // per_launch) % 2
+            retire(slot)
+            cams, suns = zip(*[hs_frame(i) for i in group])
+            with torch.cuda.stream(streams[slot]):
+                ctxs[slot].render_batch(desc, list(cams), [tuple(s) for s in suns], bufs[slot].data_ptr(), stream=streams[slot].cuda_stream)
+                host[slot][:len(group) * n_img].copy_(bufs[slot][:len(group) * n_img], non_blocking=True)
+            held[slot] = group
+        retire(0)
+        retire(1)
+    finally:
+        for st in streams:
+            st.synchronize()
+        ctxs[1].close()
     return out

@@ -564,8 +564,8 @@ def test_sequence_flow_frames_in_flight_match_the_oracle(dsrt, gpu_ctx, oracle, 
     """BASELINE.json configs[4], the flow of `bench.py --sequence` (deep-space-ray-tracer_amd/sequence.py; the reference's frame loop is
     src/main.cpp:310-431): the scene resident, 4 frames in flight on separate streams and contexts that SHARE the scene, images
     copied to pinned host memory -- over 7 poses including the far end (0), the middle (70) and the near end (98), every frame
-    compared byte for byte with the oracle.  Then the same frames through the library's one-process path (dsrt_multi_render_sequence:
-    three ranks, here all on GPU 0, frames dealt round-robin, two in flight per rank)."""
+    compared byte for byte with the oracle.  Then the same frames as batch launches (sequence.render_batches) and through the library's
+    one-process path (dsrt_multi_render_sequence: three ranks, here all on GPU 0, frames dealt round-robin, each rank's as batch launches)."""
     from dsrt_amd import sequence
     _, hs, poses = _station_scene(dsrt, tmp_path, 20000)
     W, H, spp, depth = 320, 180, 16, 50
@@ -594,6 +594,10 @@ def test_sequence_flow_frames_in_flight_match_the_oracle(dsrt, gpu_ctx, oracle, 
                 gpu_ctx.set_camera_sun(cam, sun)
                 alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
                 assert np.array_equal(got[i], alone), i
+    batched = sequence.render_batches(dsrt, gpu_ctx, frame, frames[::-1], W, H, spp, depth, per_launch=3)      # three launches, two contexts in turn
+    assert sorted(batched) == frames
+    for i in frames:
+        assert np.array_equal(batched[i], want[i]), f"batched: frame {i}"
     multi = dsrt.Multi([0, 0, 0], frames_in_flight=2)
     assert not multi.uses_rccl                           # ranks share a device here: copies stand in for the collective
     multi.upload(hs.view(cam0, sun0))
