@@ -678,6 +678,23 @@ int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const 
     return DSRT_OK;
 }
 
+int dsrt_render_batch_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz, uint8_t* h_rgb8,
+                              DsrtStats* stats) {
+    return dsrt::guarded("dsrt_render_batch_to_host", [&]() -> int {
+    if (!ctx || !desc || !h_rgb8 || frames < 1) { set_error("dsrt_render_batch_to_host: null argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)desc->width * desc->height * 3 * (size_t)frames;
+    DevBuf<uint8_t> d8;
+    int rc = d8.alloc(bytes);
+    if (rc) return rc;
+    DsrtStats local;
+    rc = dsrt_render_batch(ctx, desc, frames, cameras, sun_dirs_xyz, d8.p, nullptr, nullptr, stats ? stats : &local);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h_rgb8, d8.p, bytes, hipMemcpyDeviceToHost));
+    return DSRT_OK;
+    });
+}
+
 int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h_rgb8, float* h_f32, DsrtStats* stats) {
     return dsrt::guarded("dsrt_render_to_host", [&]() -> int {
     if (!ctx || !desc || !h_rgb8) { set_error("dsrt_render_to_host: null argument"); return DSRT_ERR_INVALID; }

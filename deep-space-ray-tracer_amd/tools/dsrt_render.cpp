@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
         char names[4096];
         const int bad = dsrt_host_scene_texture_failures(hs, names, sizeof names);
         if (bad) {
-            std::fprintf(stderr, "dsrt_render: %d texture map(s) could not be decoded (PNM and non-interlaced PNG only; the reference's stb_image also reads JPEG/BMP/TGA...);\n"
+            std::fprintf(stderr, "dsrt_render: %d texture map(s) could not be decoded (GIF, PSD, PIC, HDR and CMYK JPEG are not read here; the reference's stb_image reads them);\n"
                                  "they render as the reference's 1x1 white fallback, i.e. NOT like the reference would:\n%s", bad, names);
             if (strict_textures) return 3;
         }
@@ -89,9 +89,13 @@ int main(int argc, char** argv) {
 
     DsrtContext* ctx = nullptr;
     if (dsrt_ctx_create(0, &ctx) != DSRT_OK) return fail("creating the device context");
-    bool uploaded = false;
-    std::vector<uint8_t> fb((size_t)width * height * 3);
+    // The reference's loop renders frame after frame (src/main.cpp:310-431).  Here the poses of a run are rendered as batch launches
+    // (dsrt_render_batch_to_host: up to 32 frames as ONE pool of work, include/dsrt.h) and written out in pose order afterwards: each
+    // frame's image is byte for byte what a launch of its own would give, the run is simply not held up by every frame's tail.
     const size_t last = count < 0 ? poses.size() : std::min(poses.size(), (size_t)(first + count));
+    std::vector<size_t> ids;
+    std::vector<GPUCamera> cams;
+    std::vector<float> suns;
     for (size_t i = (size_t)first; i < last; ++i) {
         DsrtFrame fr;
         dsrt_pose_to_frame(&poses[i], &fr);
@@ -100,21 +104,33 @@ int main(int argc, char** argv) {
         GPUCamera cam;
         const float origin[3] = {0.0f, 0.0f, 0.0f};
         if (dsrt_camera_look_at(&cam, fr.cam_in_model, origin, 40.0f, width, height, spp, depth) != DSRT_OK) return fail("camera");
-        if (!uploaded) {
+        if (ids.empty()) {
             dsrt_scene_set_frame(&scene, &cam, fr.sun_dir_model);
             if (dsrt_scene_upload(ctx, &scene) != DSRT_OK) return fail("uploading the scene");
-            uploaded = true;
-        } else if (dsrt_scene_set_camera_sun(ctx, &cam, fr.sun_dir_model) != DSRT_OK) return fail("updating the camera");
-        DsrtRenderDesc d;
-        std::memset(&d, 0, sizeof d);
-        d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337; d.rng_mode = rng_mode;
+        }
+        ids.push_back(i); cams.push_back(cam);
+        suns.insert(suns.end(), fr.sun_dir_model, fr.sun_dir_model + 3);
+    }
+    DsrtRenderDesc d;
+    std::memset(&d, 0, sizeof d);
+    d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337; d.rng_mode = rng_mode;
+    const size_t image_bytes = (size_t)width * height * 3;
+    size_t per_launch = 32;
+    while (per_launch > 1 && (unsigned long long)per_launch * width * height * (rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;
+    std::vector<uint8_t> fb(image_bytes * std::min(per_launch, std::max<size_t>(ids.size(), 1)));
+    for (size_t k = 0; k < ids.size(); k += per_launch) {
+        const size_t n = std::min(per_launch, ids.size() - k);
         DsrtStats st;
-        if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, &st) != DSRT_OK) return fail("rendering");
-        char name[64];
-        std::snprintf(name, sizeof name, png ? "/frame_%04zu.png" : "/frame_%04zu.ppm", i);
-        const std::string path = out_dir + name;
-        if ((png ? dsrt_write_png(path.c_str(), fb.data(), width, height) : dsrt_write_ppm(path.c_str(), fb.data(), width, height)) != DSRT_OK) return fail("writing the frame");
-        std::printf("  kernel %.3f ms (%.1f Msamples/s)\nSaved %s\n", st.kernel_ms, (double)width * height * spp / (st.kernel_ms * 1e3), path.c_str());
+        if (dsrt_render_batch_to_host(ctx, &d, (int)n, cams.data() + k, suns.data() + 3 * k, fb.data(), &st) != DSRT_OK) return fail("rendering");
+        std::printf("\nframes %zu..%zu: kernel %.3f ms (%.1f Msamples/s)\n", ids[k], ids[k + n - 1], st.kernel_ms, (double)n * width * height * spp / (st.kernel_ms * 1e3));
+        for (size_t q = 0; q < n; ++q) {
+            char name[64];
+            std::snprintf(name, sizeof name, png ? "/frame_%04zu.png" : "/frame_%04zu.ppm", ids[k + q]);
+            const std::string path = out_dir + name;
+            const uint8_t* img = fb.data() + q * image_bytes;
+            if ((png ? dsrt_write_png(path.c_str(), img, width, height) : dsrt_write_ppm(path.c_str(), img, width, height)) != DSRT_OK) return fail("writing the frame");
+            std::printf("Saved %s\n", path.c_str());
+        }
     }
     dsrt_ctx_destroy(ctx);
     dsrt_host_scene_destroy(hs);

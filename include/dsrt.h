@@ -244,6 +244,10 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
  */
 int dsrt_render_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz,
                       uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats);
+/* The same with the images delivered to HOST memory (frames * width*height*3 bytes), synchronously: for hosts without device code of their own,
+ * like the reference's main.cpp. */
+int dsrt_render_batch_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz,
+                              uint8_t* h_rgb8, DsrtStats* stats);
 
 /* Root rank, after a gather: tile-major shards [shard][tile][tile*tile*3] -> image-order rgb8. */
 int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image,
