@@ -538,6 +538,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
     // tiles that see geometry and the number of tiles in the order.
     const size_t pre_stride = (size_t)t.mine + 64;          // per frame: tile costs / order, then the sched words
+    if (pre_stride * (size_t)frames >= ((size_t)1 << 32)) { set_error("dsrt_render_batch: too many tiles in one batch (split the sequence)"); return DSRT_ERR_INVALID; }
     for (DevBuf<uint32_t>* b : {&ctx->tile_cost, &ctx->tile_order, &ctx->tile_work, &ctx->tile_tmp}) {      // each by its own size: a failed
         const size_t want = (b == &ctx->tile_cost || b == &ctx->tile_order) ? pre_stride * (size_t)frames : pre_stride;
         if (b->n < want) { int rc = b->alloc(want); if (rc) return rc; }                                    // allocation leaves no stale sibling
