@@ -641,6 +641,25 @@ def main():
         pinned.copy_(part[:W * H * 3], non_blocking=True)
         torch.cuda.synchronize()
         extras["frame_to_pinned_host_ms"] = (time.perf_counter() - t0) * 1e3
+        # the headline frame four times over as ONE batch launch (dsrt_render_batch): what is left of the step when a frame's last chains run
+        # under the next frame's bulk.  The headline itself stays one launch per step, each waited for.
+        try:
+            nb = 4
+            batch_img = torch.zeros(nb * W * H * 3, dtype=torch.uint8, device=dev)
+            bdesc = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries)
+            sun = tuple(fr.sun_dir_model)
+            ctx.render_batch(bdesc, [cam] * nb, [sun] * nb, batch_img.data_ptr(), stream=stream, want_stats=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.render_batch(bdesc, [cam] * nb, [sun] * nb, batch_img.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            per_frame = (time.perf_counter() - t0) * 1e3 / nb
+            same = all(bool(torch.equal(batch_img[k * W * H * 3:(k + 1) * W * H * 3], part[:W * H * 3])) for k in range(nb))
+            extras["headline_frame_x4_as_one_batch_launch"] = {"ms_per_frame": per_frame, "Msamples/s": W * H * spp / per_frame / 1e3,
+                                                               "every_image_equals_the_single_launch_image": same}
+            del batch_img
+        except Exception as e:  # noqa: BLE001 -- an extra never stops the bench
+            extras["headline_frame_x4_as_one_batch_launch"] = {"error": str(e)[:200]}
 
     # ---- roofline: calibration kernels live, PMC counters of this workload from child passes ----
     roof = None
