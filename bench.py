@@ -247,7 +247,7 @@ def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, 
     pipe.close()
     if rank == 0:
         print(json.dumps({
-            "metric": "frames/s (pose sequence, 1920x1080, scene resident, frames in flight on separate streams, images copied to pinned host memory)",
+            "metric": f"frames/s (pose sequence, {W}x{H}, scene resident, frames in flight on separate streams, images copied to pinned host memory)",
             "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": pipe.K,
             "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
@@ -304,7 +304,7 @@ def run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, dep
     ctxs[1].close()
     if rank == 0:
         print(json.dumps({
-            "metric": "frames/s (pose sequence, 1920x1080, scene resident, frames rendered as batch launches, images copied to pinned host memory)",
+            "metric": f"frames/s (pose sequence, {W}x{H}, scene resident, frames rendered as batch launches, images copied to pinned host memory)",
             "value": len(frames) / dt, "unit": "frames/s", "n_gpus": world, "steps": len(frames), "warmup": 4,
             "ms_per_step": dt / len(frames) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
