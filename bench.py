@@ -265,7 +265,7 @@ def run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, dep
     pinned host memory meanwhile."""
     import torch
     import torch.distributed as dist
-    B = args.batch
+    B = max(1, min(args.batch, ((1 << 32) - 1) // (W * H * (16 if args.rng_mode == 1 else 1))))      # 32-bit work-item numbers inside a launch (include/dsrt.h)
     ids = sorted(mine, reverse=True)
     groups = [ids[k:k + B] for k in range(0, len(ids), B)]
     cams = {i: frame_scene(i) for i in ids}
