@@ -194,6 +194,11 @@ def shard_layout(desc):
     return {"tiles_total": total.value, "tiles_this_shard": mine.value, "tiles_per_shard_padded": padded.value, "rgb8_bytes_padded": nbytes.value}
 
 
+def selftest_rccl_gather(device=0, nbytes=1 << 20):
+    """dsrt_selftest_rccl_gather: a one-rank RCCL communicator and one checked ncclGather on `device`."""
+    _check(lib.dsrt_selftest_rccl_gather(int(device), int(nbytes)), "dsrt_selftest_rccl_gather")
+
+
 def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_bytes=19 << 20, iters=2000, device=0):
     """Gather-rate calibration kernel (include/dsrt.h): returns {"ms", "records", "Grecords_per_s"}."""
     ms, rec = C.c_float(), C.c_double()

@@ -107,7 +107,7 @@ EXPORTS = [
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
-    "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
+    "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_selftest_rccl_gather", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
     "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_render", "dsrt_render_batch", "dsrt_render_batch_to_host", "dsrt_deinterleave_tiles", "dsrt_render_to_host",
     "dsrt_selftest_math", "dsrt_selftest_philox", "dsrt_microbench_gather", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
 ]
@@ -156,6 +156,7 @@ def load():
     sig("dsrt_multi_destroy", None, [vp])
     sig("dsrt_multi_count", C.c_int, [vp])
     sig("dsrt_multi_uses_rccl", C.c_int, [vp])
+    sig("dsrt_selftest_rccl_gather", C.c_int, [C.c_int, C.c_size_t])
     sig("dsrt_multi_scene_upload", C.c_int, [vp, P(GPUScene)])
     sig("dsrt_multi_render_frame", C.c_int, [vp, P(DsrtRenderDesc), P(GPUCamera), P(C.c_float), vp, P(C.c_float), P(C.c_double)])
     sig("dsrt_multi_render_sequence", C.c_int, [vp, P(DsrtRenderDesc), P(GPUCamera), P(C.c_float), C.c_int, P(vp), P(C.c_double)])

@@ -163,6 +163,37 @@ int dsrt_multi_create(const int* devices, int n, int frames_in_flight, DsrtMulti
 int dsrt_multi_count(const DsrtMulti* m) { return m ? (int)m->ranks.size() : 0; }
 int dsrt_multi_uses_rccl(const DsrtMulti* m) { return m && m->rccl ? 1 : 0; }
 
+// The smallest thing that exercises the collective on whatever is there: a one-rank RCCL communicator on `device` and one ncclGather of
+// `bytes` bytes through it (rank 0's block lands at offset 0 of the receive buffer).  On a one-GPU box this is all of the RCCL path that
+// can run -- library load, communicator, the call and its stream ordering; the N-rank gather itself needs N devices.
+int dsrt_selftest_rccl_gather(int device, size_t bytes) {
+    return dsrt::guarded("dsrt_selftest_rccl_gather", [&]() -> int {
+        if (bytes == 0 || bytes > ((size_t)1 << 30)) { set_error("dsrt_selftest_rccl_gather: 1 byte to 1 GiB"); return DSRT_ERR_INVALID; }
+        HIP_TRY(hipSetDevice(device));
+        ncclComm_t comm = nullptr;
+        const int devs[1] = {device};
+        NCCL_TRY(ncclCommInitAll(&comm, 1, devs));
+        uint8_t *send = nullptr, *recv = nullptr;
+        hipStream_t stream = nullptr;
+        int rc = DSRT_OK;
+        std::vector<uint8_t> host(bytes), back(bytes);
+        for (size_t i = 0; i < bytes; ++i) host[i] = (uint8_t)(i * 131u + 7u);
+        if (!hip_ok(hipMalloc((void**)&send, bytes), "hipMalloc") || !hip_ok(hipMalloc((void**)&recv, bytes), "hipMalloc") ||
+            !hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreateWithFlags") ||
+            !hip_ok(hipMemcpyAsync(send, host.data(), bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync") ||
+            !hip_ok(hipMemsetAsync(recv, 0, bytes, stream), "hipMemsetAsync")) rc = DSRT_ERR_HIP;
+        if (rc == DSRT_OK && !nccl_ok(ncclGather(send, recv, bytes, ncclUint8, 0, comm, stream), "ncclGather")) rc = DSRT_ERR_COMM;
+        if (rc == DSRT_OK && (!hip_ok(hipMemcpyAsync(back.data(), recv, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync") ||
+                              !hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize"))) rc = DSRT_ERR_HIP;
+        if (rc == DSRT_OK && std::memcmp(host.data(), back.data(), bytes) != 0) { set_error("dsrt_selftest_rccl_gather: gathered bytes differ"); rc = DSRT_ERR_COMM; }
+        if (stream) (void)hipStreamDestroy(stream);
+        if (send) (void)hipFree(send);
+        if (recv) (void)hipFree(recv);
+        (void)ncclCommDestroy(comm);
+        return rc;
+    });
+}
+
 int dsrt_multi_scene_upload(DsrtMulti* m, const GPUScene* host_scene) {
     if (!m || !host_scene) { set_error("dsrt_multi_scene_upload: null argument"); return DSRT_ERR_INVALID; }
     return dsrt::guarded("dsrt_multi_scene_upload", [&]() -> int {

@@ -277,6 +277,9 @@ int  dsrt_multi_create(const int* devices, int n, int frames_in_flight, DsrtMult
 void dsrt_multi_destroy(DsrtMulti* m);
 int  dsrt_multi_count(const DsrtMulti* m);
 int  dsrt_multi_uses_rccl(const DsrtMulti* m);
+/* Self-test: a one-rank RCCL communicator on `device` and one ncclGather of `bytes` bytes through it, checked.  All of the collective
+ * path that can run on a single GPU. */
+int  dsrt_selftest_rccl_gather(int device, size_t bytes);
 /* The scene (HOST pointers, reference layouts) is converted and made resident once per device. */
 int  dsrt_multi_scene_upload(DsrtMulti* m, const GPUScene* host_scene);
 /* ONE frame over all ranks: interleaved screen tiles (tile g -> rank g mod N), one ncclGather of the equal-sized compact

@@ -649,6 +649,29 @@ def test_batch_launch_gives_every_frame_its_own_image(dsrt, gpu_ctx, oracle, tmp
         gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, collect_counters=1), list(cams), list(suns), rgb.data_ptr())
 
 
+def test_rccl_gather_runs_on_the_one_gpu_there_is(dsrt, gpu_ctx):
+    """What of config 4's collective can execute on a one-GPU box: RCCL itself.  (1) the library's own path -- a one-rank communicator
+    (ncclCommInitAll) and one ncclGather through it, checked byte for byte (dsrt_selftest_rccl_gather); (2) the path bench.py takes --
+    torch.distributed's `nccl` backend (= RCCL) with world size 1 and dist.gather of a shard buffer.  The N-rank gather needs N devices;
+    its receive layout, padding and de-interleave are what the 8-rank layout tests (one GPU, copies) and the gloo tests cover."""
+    import torch
+    import torch.distributed as dist
+    dsrt.selftest_rccl_gather(0, 1 << 20)
+    dsrt.selftest_rccl_gather(0, 777_601)                            # one rank's padded share of a 1080p frame, odd size
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            part = torch.arange(777_600, dtype=torch.int64, device="cuda").to(torch.uint8)
+            bucket = [torch.empty_like(part)]
+            dist.gather(part, bucket, dst=0)
+            torch.cuda.synchronize()
+            assert torch.equal(bucket[0], part)
+        finally:
+            dist.destroy_process_group()
+
+
 def test_eight_ranks_at_the_1080p_layout(dsrt, gpu_ctx, oracle, tmp_path):
     """BASELINE.json configs[3]'s layout on one GPU: 1920x1080 in 8x8 tiles is 32,400 tiles, 4,050 per rank with 8 ranks (equal here;
     the padded case is covered at 1918x1078 -> 32,400 tiles too but ragged edges, and by the CPU layout tests).  Eight shards rendered
