@@ -318,7 +318,8 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
         while (per_launch > 1 && (unsigned long long)per_launch * d.width * d.height * (d.rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;
         for (Rank& k : m->ranks) {
             HIP_TRY(hipSetDevice(k.device));
-            for (Slot& s : k.slots) { if ((rc = ensure_slot_images(s, image_bytes * per_launch))) return rc; s.frame = -1; }
+            const size_t use = std::min<size_t>(k.slots.size(), 2);             // two launches in turn are all that overlap: image buffers for those slots only
+            for (size_t si = 0; si < use; ++si) { Slot& s = k.slots[si]; if ((rc = ensure_slot_images(s, image_bytes * per_launch))) return rc; s.frame = -1; }
         }
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::vector<std::vector<int>>> held((size_t)n);                              // per rank, per slot: the frames whose images the slot holds
@@ -344,7 +345,7 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
                 if (next[(size_t)r] >= v.size()) continue;
                 any = true;
                 Rank& k = m->ranks[(size_t)r];
-                const size_t si = turn[(size_t)r]++ % k.slots.size();
+                const size_t si = turn[(size_t)r]++ % std::min<size_t>(k.slots.size(), 2);
                 Slot& s = k.slots[si];
                 HIP_TRY(hipSetDevice(k.device));
                 if ((rc = retire(r, si))) return rc;
