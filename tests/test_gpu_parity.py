@@ -642,6 +642,22 @@ def test_batch_launch_gives_every_frame_its_own_image(dsrt, gpu_ctx, oracle, tmp
             gpu_ctx.set_camera_sun(cams[k], suns[k])
             alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
             assert np.array_equal(got1[k], alone), f"rng_mode 1, frame {i}"
+    # production size: 12 poses at 1920x1080 in one launch (25 M pixels: output indices far beyond one frame's), each against its own launch
+    W, H, spp = 1920, 1080, 8
+    big = list(range(0, 99, 9)) + [98]
+
+    def frame_big(i):
+        fr = dsrt.pose_to_frame(poses[i])
+        return dsrt.frame_camera(fr, 40.0, W, H, spp, depth), tuple(fr.sun_dir_model)
+    cams, suns = zip(*[frame_big(i) for i in big])
+    rgb = torch.zeros(len(big) * H * W * 3, dtype=torch.uint8, device="cuda")
+    gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth), list(cams), list(suns), rgb.data_ptr(), stream=stream, want_stats=True)
+    got = rgb.cpu().numpy().reshape(len(big), H, W, 3)
+    for k, i in enumerate(big):
+        gpu_ctx.set_camera_sun(cams[k], suns[k])
+        alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth))
+        assert np.array_equal(got[k], alone), f"1080p batch, frame {i}"
+    assert got[-1].max() > 0
     # what a batch cannot be: sharded, counted, or bigger than its 32-bit indices
     with pytest.raises(dsrt.DsrtError):
         gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, shard_rank=0, shard_count=2), list(cams), list(suns), rgb.data_ptr())
