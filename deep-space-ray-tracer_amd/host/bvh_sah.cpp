@@ -12,7 +12,9 @@
 // nodes numbered in pre-order like the reference's, so the depth-first re-layout in device_api.hip sees the same shape.
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <limits>
+#include <thread>
 
 #include "host_internal.hpp"
 
@@ -31,14 +33,15 @@ struct Box {
 constexpr int kBins = 32;
 constexpr int kLeafMax = 4;
 
+constexpr int kParallelMin = 1 << 15;       // ranges smaller than this are not worth a thread
+
 struct SahBuilder {
     const std::vector<Box>& tri_box;
     const std::vector<float>& centroid;
     std::vector<int>& order;
-    std::vector<GPUBVHNode>& nodes;
-    int height = 0;
 
-    int build(int start, int end, int level) {
+    // as in bvh_median.cpp: the two halves of a large range are built on two threads into node vectors of their own and spliced in pre-order
+    int build(int start, int end, int level, std::vector<GPUBVHNode>& nodes, int& height, int fork) {
         const int self = (int)nodes.size();
         nodes.emplace_back();
         if (level > height) height = level;
@@ -106,9 +109,33 @@ struct SahBuilder {
         }
         nodes[self].tri_offset = 0;
         nodes[self].tri_count = 0;
-        const int l = build(start, mid, level + 1);
+        if (fork > 0 && end - start >= kParallelMin) {
+            std::vector<GPUBVHNode> left, right;
+            left.reserve((size_t)(mid - start) * 2 / 3 + 64); right.reserve((size_t)(end - mid) * 2 / 3 + 64);
+            int hl = 0, hr = 0;
+            std::exception_ptr failed;
+            std::thread worker([&]() { try { build(start, mid, level + 1, left, hl, fork - 1); } catch (...) { failed = std::current_exception(); } });
+            try { build(mid, end, level + 1, right, hr, fork - 1); } catch (...) { worker.join(); throw; }
+            worker.join();
+            if (failed) std::rethrow_exception(failed);
+            auto splice = [&](const std::vector<GPUBVHNode>& sub) {
+                const int base = (int)nodes.size();
+                for (GPUBVHNode n : sub) {
+                    if (n.tri_count == 0 && n.left >= 0) { n.left += base; n.right += base; }
+                    nodes.push_back(n);
+                }
+                return base;
+            };
+            const int l = splice(left);
+            nodes[self].left = l;
+            const int r = splice(right);
+            nodes[self].right = r;
+            height = std::max(height, std::max(hl, hr));
+            return self;
+        }
+        const int l = build(start, mid, level + 1, nodes, height, 0);
         nodes[self].left = l;
-        const int r = build(mid, end, level + 1);
+        const int r = build(mid, end, level + 1, nodes, height, 0);
         nodes[self].right = r;
         return self;
     }
@@ -153,9 +180,11 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
     hs->tri_indices.resize(n);
     for (size_t i = 0; i < n; ++i) hs->tri_indices[i] = (int)i;
     hs->nodes.reserve(n);
-    SahBuilder b{tri_box, centroid, hs->tri_indices, hs->nodes};
-    b.build(0, (int)n, 1);
-    hs->bvh_height = b.height;
+    SahBuilder b{tri_box, centroid, hs->tri_indices};
+    int height = 0, fork = 0;
+    for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 5; t >>= 1) ++fork;
+    b.build(0, (int)n, 1, hs->nodes, height, fork);
+    hs->bvh_height = height;
     hs->bvh_valid = true;
     if (hs->bvh_height - 1 > 64) {
         dsrt::set_error("SAH BVH needs a traversal stack deeper than 64 entries");

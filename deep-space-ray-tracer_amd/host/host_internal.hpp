@@ -7,6 +7,8 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "scene_model.hpp"
@@ -35,6 +37,13 @@ bool decode_tga(const std::vector<uint8_t>& file_bytes, RgbImage& img);
 
 // half-width by which the non-parity BVH builders (bvh_sah.cpp, csrc/bvh_lbvh.hip) widen a triangle box that has zero thickness on an axis
 inline float flat_box_pad(float scene_extent) { return scene_extent > 0.0f ? scene_extent * (1.0f / 4096.0f) : 1.0e-6f; }
+
+// threads the host BVH builders may use: the machine's, or DSRT_BUILD_THREADS if the environment sets it (1 = build on the calling thread)
+inline unsigned builder_threads() {
+    if (const char* e = std::getenv("DSRT_BUILD_THREADS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) return (unsigned)v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw ? hw : 1u;
+}
 
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);
