@@ -143,7 +143,7 @@ extern "C" int dsrt_host_scene_build_bvh(DsrtHostScene* hs) {
     hs->nodes.reserve(n * 2);
     Builder b{tri_box, centroid, hs->tri_indices};
     int height = 0, fork = 0;
-    for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 5; t >>= 1) ++fork;      // 2^fork threads at most
+    for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 4; t >>= 1) ++fork;      // 2^fork threads, 16 at most
     b.build(0, (int)n, 1, hs->nodes, height, fork);
     hs->bvh_height = height;
     hs->bvh_valid = true;

@@ -182,7 +182,7 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
     hs->nodes.reserve(n);
     SahBuilder b{tri_box, centroid, hs->tri_indices};
     int height = 0, fork = 0;
-    for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 5; t >>= 1) ++fork;
+    for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 4; t >>= 1) ++fork;
     b.build(0, (int)n, 1, hs->nodes, height, fork);
     hs->bvh_height = height;
     hs->bvh_valid = true;
