@@ -158,3 +158,28 @@ def test_gpu_built_lbvh_is_a_valid_tree_and_the_kernel_matches_the_oracle_on_it(
     hs2, _, _, _, _, _ = _scene(dsrt, name, "lbvh")
     b = hs2.arrays()
     assert np.array_equal(b["idx"], idx) and b["nodes"].tobytes() == nodes.tobytes()
+
+
+@pytest.mark.parametrize("kind", ["median", "sah"])
+def test_threaded_host_builders_give_the_one_thread_tree(dsrt, tmp_path, kind):
+    """Ranges of 32,768 triangles and more are built half on another thread and spliced in pre-order (host/bvh_median.cpp, bvh_sah.cpp).  The
+    one-thread build of the median tree is what the reference-made goldens pin (tests/test_host_golden.py, small scenes); this holds the
+    threaded build to it on a mesh big enough to fork three levels deep: same nodes, same triangle permutation, same height."""
+    from dsrt_amd import meshgen
+    obj = tmp_path / "iss_150k.obj"
+    meshgen.generate(obj, 150000)
+    got = {}
+    old = os.environ.get("DSRT_BUILD_THREADS")
+    try:
+        for threads in ("1", "8"):
+            os.environ["DSRT_BUILD_THREADS"] = threads
+            hs = dsrt.HostScene().add_obj(obj)
+            hs.build_bvh(kind)
+            a = hs.arrays()
+            got[threads] = (a["nodes"].tobytes(), a["idx"].tobytes(), hs.stack_need)
+    finally:
+        if old is None:
+            os.environ.pop("DSRT_BUILD_THREADS", None)
+        else:
+            os.environ["DSRT_BUILD_THREADS"] = old
+    assert got["1"] == got["8"]
