@@ -212,13 +212,17 @@ def spawn_distributed(n):
     sys.exit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
 
 
-def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name):
+def run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name, hs_nodes_root_box):
     """BASELINE.json configs[4]: the whole pose file as one job (deep-space-ray-tracer_amd/sequence.py)."""
     import torch
     import torch.distributed as dist
     from dsrt_amd import sequence
     frames = [i for i in range(len(poses)) if not d.pose_to_frame(poses[i]).skipped]
-    mine = sequence.frame_assignment(frames, rank, world, args.split)
+    # whole frames are dealt by estimated cost (nearest poses cost 30 times the farthest), not round-robin: sequence.approach_cost
+    nodes = hs_nodes_root_box
+    radius = 0.5 * max(nodes[1][a] - nodes[0][a] for a in range(3))
+    costs = [sequence.approach_cost(d.pose_to_frame(poses[i]).sep_m, radius) for i in frames] if args.deal == "cost" else None
+    mine = sequence.frame_assignment(frames, rank, world, args.split, costs)
     shard = (rank, world, shard_mod.gather_to_root) if (world > 1 and args.split == "tiles") else None
     if args.batch > 0 and shard is None:
         return run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
@@ -310,7 +314,7 @@ def run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, dep
             "data": "synthetic", "msamples_per_s": len(frames) * W * H * spp / dt / 1e6,
             "config": {"workload": f"{mesh_name}: {n_tris} triangles, all {len(frames)} poses of rendezvous_1s_dt0_01s.txt, {W}x{H} @ {spp} spp, "
                                    f"max_depth {depth}, rng_mode {args.rng_mode}", "frames": len(frames), "spp": spp, "rng_mode": args.rng_mode, "bvh": args.bvh,
-                       "frames_per_launch": B, "launches_per_rank": len(groups), "split": "frames" if world > 1 else "single GPU",
+                       "frames_per_launch": B, "launches_per_rank": len(groups), "split": "frames" if world > 1 else "single GPU", "frames_dealt_by": args.deal,
                        "parallelism": "poses dealt round-robin to ranks, no data-path collective" if world > 1 else "one GPU"}}), flush=True)
 
 
@@ -339,6 +343,7 @@ def main():
     ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
                     help="median = the reference's tree (parity; the headline). sah = non-parity fast mode (SURVEY.md 8(f) n4), labelled in the output")
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
+    ap.add_argument("--deal", choices=["cost", "round-robin"], default="cost", help="--sequence on N GPUs, --split frames: how whole frames are dealt to ranks")
     ap.add_argument("--batch", type=int, default=99, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
     ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -472,7 +477,9 @@ def main():
         return
 
     if args.sequence:
-        run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name)
+        root = hs.arrays()["nodes"][0]
+        root_box = ([float(v) for v in root["bbox_min"]], [float(v) for v in root["bbox_max"]])
+        run_sequence(args, d, ctx, poses, frame_scene, shard_mod, W, H, spp, depth, rank, world, dev, n_tris, mesh_name, root_box)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -654,6 +654,13 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     return DSRT_OK;
 }
 
+int dsrt_ctx_scene_bounds(const DsrtContext* ctx, float lo[3], float hi[3]) {
+    if (!ctx || !lo || !hi) { set_error("dsrt_ctx_scene_bounds: null argument"); return DSRT_ERR_INVALID; }
+    if (!ctx->scene || !ctx->scene->valid) { set_error("dsrt_ctx_scene_bounds: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    for (int a = 0; a < 3; ++a) { lo[a] = ctx->scene->view.root_lo[a]; hi[a] = ctx->scene->view.root_hi[a]; }
+    return DSRT_OK;
+}
+
 int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats) {
     return render_impl(ctx, desc, d_rgb8, d_f32, stream, stats, nullptr);
 }

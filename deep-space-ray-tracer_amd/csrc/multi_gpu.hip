@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <set>
 #include <string>
@@ -304,14 +305,37 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
         DsrtRenderDesc d = *desc_in;
         d.shard_count = 0; d.shard_rank = 0;                        // whole frames
         const size_t image_bytes = (size_t)d.width * d.height * 3;
-        // Rank r renders frames r, r + N, ... in batch launches (dsrt_render_batch: the frames of a launch are one pool of work, so the serial
-        // chains of one frame run under the bulk of the others), nearest poses first when the caller's order ends near, as the pose file's
-        // does; at most kGroup frames per launch, the rank's slots taking the launches in turn so that one launch's images travel to the
+        // Every rank renders its frames in batch launches (dsrt_render_batch: the frames of a launch are one pool of work, so the serial
+        // chains of one frame run under the bulk of the others), costliest first; at most kGroup frames per launch, the rank's slots taking the launches in turn so that one launch's images travel to the
         // host while the next one renders.
         constexpr int kGroup = 32;
         int rc;
+        // Whole frames are dealt by estimated cost, not round-robin: on an approach the nearest frames cost 30 times the farthest, and
+        // round-robin hands one rank the nearest of all (8 ranks: a quarter of the node idle).  Estimate: 1 / (distance from the camera to the
+        // scene's centre + the scene's radius); longest-processing-time first -- frames in order of falling estimate, each to the rank with
+        // the least so far (deep-space-ray-tracer_amd/sequence.py does the same for the one-process-per-GPU job).
         std::vector<std::vector<int>> mine((size_t)n);
-        for (int i = n_frames - 1; i >= 0; --i) mine[(size_t)(i % n)].push_back(i);          // last (nearest) first
+        {
+            float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            if ((rc = dsrt_ctx_scene_bounds(m->ranks[0].slots[0].ctx, lo, hi))) return rc;
+            const double centre[3] = {0.5 * ((double)lo[0] + hi[0]), 0.5 * ((double)lo[1] + hi[1]), 0.5 * ((double)lo[2] + hi[2])};
+            const double radius = 0.5 * std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]});
+            std::vector<double> cost((size_t)n_frames);
+            std::vector<int> by_cost((size_t)n_frames);
+            for (int i = 0; i < n_frames; ++i) {
+                const double dx = cams[i].origin.x - centre[0], dy = cams[i].origin.y - centre[1], dz = cams[i].origin.z - centre[2];
+                cost[(size_t)i] = 1.0 / (std::sqrt(dx * dx + dy * dy + dz * dz) + radius + 1e-9);
+                by_cost[(size_t)i] = i;
+            }
+            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+            std::vector<double> load((size_t)n, 0.0);
+            for (int i : by_cost) {                                                              // costliest first: also the order inside a rank's launches
+                size_t r = 0;
+                for (size_t q = 1; q < (size_t)n; ++q) if (load[q] < load[r]) r = q;
+                load[r] += cost[(size_t)i];
+                mine[r].push_back(i);
+            }
+        }
         size_t per_launch = 1;
         for (const auto& v : mine) per_launch = std::max(per_launch, std::min(v.size(), (size_t)kGroup));
         // 32-bit work-item numbers inside a launch (include/dsrt.h): fewer frames per launch for very large images

@@ -20,10 +20,33 @@ With more than one rank (one process per GPU, torch.distributed) the job splits 
 import numpy as np
 
 
-def frame_assignment(frame_ids, rank, world, split):
-    """The frames this rank works on: all of them (tile split: every rank renders its tiles of every frame) or every world-th."""
+def approach_cost(sep_m, scene_radius_m):
+    """Relative cost of a frame of the approach: 1 / (distance to the model's centre + the model's radius).  Measured on the stand-in station
+    at 1080p x 250 (tools/frame_costs_probe.py): dealing frames by this estimate keeps 8 ranks within 5-9 % of each other, round-robin
+    dealing -- the nearest frames cost 30 times the farthest, and one rank gets the nearest -- leaves 28 % of the node idle."""
+    return 1.0 / (float(sep_m) + float(scene_radius_m))
+
+
+def frame_assignment(frame_ids, rank, world, split, costs=None):
+    """The frames this rank works on: all of them (tile split: every rank renders its tiles of every frame), or its share of whole frames.
+    Without `costs` frames are dealt round-robin; with costs (one number per frame, any unit) longest-processing-time first: frames in
+    order of falling cost, each to the rank with the least so far (ties: lowest rank) -- the same answer on every rank, no communication."""
     frame_ids = list(frame_ids)
-    return frame_ids if split == "tiles" or world == 1 else frame_ids[rank::world]
+    if split == "tiles" or world == 1:
+        return frame_ids
+    if costs is None:
+        return frame_ids[rank::world]
+    costs = [float(c) for c in costs]
+    if len(costs) != len(frame_ids):
+        raise ValueError("one cost per frame")
+    load = [0.0] * world
+    mine = []
+    for k in sorted(range(len(frame_ids)), key=lambda k: (-costs[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        load[r] += costs[k]
+        if r == rank:
+            mine.append(frame_ids[k])
+    return sorted(mine)
 
 
 class FramePipeline:

@@ -226,6 +226,9 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
  *   d_f32  : optional DEVICE buffer, same indexing, 3 floats per pixel: the value multiplied by 255.99
  *            (:1028), for the L-infinity parity check.  May be NULL.
  */
+/* Bounding box of the resident scene's BVH root (all zeros without a BVH). */
+int dsrt_ctx_scene_bounds(const DsrtContext* ctx, float lo[3], float hi[3]);
+
 int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, float* d_f32, void* stream, DsrtStats* stats);
 
 /*
