@@ -269,6 +269,11 @@ class Context:
         _check(lib.dsrt_deinterleave_tiles(self._h, C.byref(desc), C.c_void_p(d_gathered_ptr), C.c_void_p(d_image_ptr),
                                            C.c_void_p(stream) if stream else None), "dsrt_deinterleave_tiles")
 
+    def deinterleave_batch(self, desc, frames, d_gathered_ptr, d_images_ptr, stream=None):
+        """dsrt_deinterleave_batch: the gathered compact buffers of sharded batch launches -> `frames` whole images."""
+        _check(lib.dsrt_deinterleave_batch(self._h, C.byref(desc), int(frames), C.c_void_p(d_gathered_ptr), C.c_void_p(d_images_ptr),
+                                           C.c_void_p(stream) if stream else None), "dsrt_deinterleave_batch")
+
     def render_to_host(self, desc, want_f32=False):
         n = desc.width * desc.height * 3
         rgb = np.zeros(n, np.uint8)

@@ -108,7 +108,7 @@ EXPORTS = [
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
     "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_selftest_rccl_gather", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
-    "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_ctx_scene_bounds", "dsrt_render", "dsrt_render_batch", "dsrt_render_batch_to_host", "dsrt_deinterleave_tiles", "dsrt_render_to_host",
+    "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_ctx_scene_bounds", "dsrt_render", "dsrt_render_batch", "dsrt_render_batch_to_host", "dsrt_deinterleave_tiles", "dsrt_deinterleave_batch", "dsrt_render_to_host",
     "dsrt_selftest_math", "dsrt_selftest_philox", "dsrt_microbench_gather", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
 ]
 
@@ -169,6 +169,7 @@ def load():
     sig("dsrt_render_batch", C.c_int, [vp, P(DsrtRenderDesc), C.c_int, P(GPUCamera), P(C.c_float), vp, vp, vp, P(DsrtStats)])
     sig("dsrt_render_batch_to_host", C.c_int, [vp, P(DsrtRenderDesc), C.c_int, P(GPUCamera), P(C.c_float), vp, P(DsrtStats)])
     sig("dsrt_deinterleave_tiles", C.c_int, [vp, P(DsrtRenderDesc), vp, vp, vp])
+    sig("dsrt_deinterleave_batch", C.c_int, [vp, P(DsrtRenderDesc), C.c_int, vp, vp, vp])
     sig("dsrt_render_to_host", C.c_int, [vp, P(DsrtRenderDesc), vp, vp, P(DsrtStats)])
     sig("dsrt_selftest_math", C.c_int, [vp, C.c_int, vp, C.c_float, vp, C.c_int])
     sig("dsrt_selftest_philox", C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp])

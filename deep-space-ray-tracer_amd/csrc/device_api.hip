@@ -456,9 +456,10 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     const int frames = batch ? batch->frames : 1;
     if (batch) {
         if (frames < 1 || !batch->cameras || !batch->sun_dirs) { set_error("dsrt_render_batch: no frames"); return DSRT_ERR_INVALID; }
-        if (desc->shard_count > 1 || desc->collect_counters || desc->checked) { set_error("dsrt_render_batch renders whole frames with the production kernel only"); return DSRT_ERR_INVALID; }
+        if (desc->collect_counters || desc->checked) { set_error("dsrt_render_batch uses the production kernel only (no counters, not checked)"); return DSRT_ERR_INVALID; }
         // 32-bit output indices and work-item numbers: frames x pixels (x 8 sample slices in rng_mode 1) stay below 2^32
-        if ((unsigned long long)frames * (unsigned long long)desc->width * desc->height * (desc->rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) {
+        const unsigned long long frame_px = desc->shard_count > 1 ? (unsigned long long)t.padded * t.tile * t.tile : (unsigned long long)desc->width * desc->height;
+        if ((unsigned long long)frames * frame_px * (desc->rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) {
             set_error("dsrt_render_batch: too many pixels in one batch (split the sequence)"); return DSRT_ERR_INVALID;
         }
     }
@@ -569,6 +570,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         HIP_TRY(launch_batch_table(ctx->batch_table.p, sched, (uint32_t)pre_stride, (uint32_t)frames, (uint32_t)(t.tile * t.tile), desc->rng_mode, f.spp,
                                    f.light_chunk_len, ctx->ctrl.p + 2, stream));
         a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = (uint32_t)frames;
+        a.batch_frame_pixels = (uint32_t)(out_pixels / (size_t)frames);        // whole images, or the padded compact shard buffers, one after another
     } else
     if ((desc->tune[3] & 3) != 1 && t.mine > 0) {
         const bool cull = (desc->tune[3] & 3) != 2 && desc->collect_counters == 0;
@@ -674,6 +676,19 @@ int dsrt_render_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, 
         const BatchInput b{frames, cameras, suns.data()};
         return render_impl(ctx, desc, d_rgb8, d_f32, stream, stats, &b);
     });
+}
+
+int dsrt_deinterleave_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const uint8_t* d_gathered, uint8_t* d_rgb8_images, void* stream) {
+    Tiling t;
+    if (!ctx || !desc || frames < 1 || !d_gathered || !d_rgb8_images || !make_tiling(*desc, t)) { set_error("dsrt_deinterleave_batch: bad argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int count = desc->shard_count > 1 ? desc->shard_count : 1;
+    const size_t part = (size_t)t.padded * t.tile * t.tile * 3, image = (size_t)desc->width * desc->height * 3;
+    // the gather of sharded batch launches: rank r's buffer holds its part of frame 0, of frame 1, ...; rank r + 1's follows `frames` parts on
+    for (int f = 0; f < frames; ++f)
+        HIP_TRY(launch_deinterleave(d_gathered + (size_t)f * part, d_rgb8_images + (size_t)f * image, desc->width, desc->height, t.tile, t.tiles_x, count,
+                                    part * (size_t)frames, (hipStream_t)stream));
+    return DSRT_OK;
 }
 
 int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image, void* stream) {

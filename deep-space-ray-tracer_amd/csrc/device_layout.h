@@ -112,7 +112,7 @@ struct RenderArgs {
     int       hot_graded;      //   1 = three levels (that share, a quarter and a sixteenth of it), 0 = one level
     const BatchFrame* batch;   // batch launch only: one entry per frame
     const uint32_t* batch_order; //   the frames' tile orders, BatchFrame::order_base apart
-    uint32_t  batch_frames;
+    uint32_t  batch_frames, batch_frame_pixels;   // frames in the launch; output pixels per frame (W*H, or a shard's padded tile buffer)
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word

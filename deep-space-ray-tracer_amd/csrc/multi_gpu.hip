@@ -7,11 +7,11 @@
 //     dsrt_shard_layout): every rank renders its tiles into a compact buffer on its own device and stream, then ONE RCCL gather
 //     over xGMI (ncclGather, equal counts because every rank's buffer is padded to ceil(tiles / N) tiles) brings them to rank 0,
 //     a small kernel restores image order there, and the image is copied to the caller's host buffer.
-//   * dsrt_multi_render_sequence   MANY frames of one scene (the pose file): frame i goes WHOLE to rank i mod N -- no collective
-//     at all, the natural shard for a sequence, and the only one that scales in rng_mode 0, where a pixel is a serial chain of spp
-//     samples whatever the number of GPUs.  Each rank renders its frames in batch launches (dsrt_render_batch:
-//     up to 32 frames as one pool of work), its slots (clones of its context: the scene is resident once per GPU) taking the launches
-//     in turn, and copies finished images to pinned host memory.
+//   * dsrt_multi_render_sequence   MANY frames of one scene (the pose file): every rank renders its interleaved tiles of EVERY frame as
+//     batch launches (dsrt_render_batch with a shard: up to 128 frames' tiles as one pool of work), one gather per launch for all its
+//     frames, de-interleave on rank 0, images to pinned host memory.  In rng_mode 0 a pixel is a serial chain of spp samples whatever
+//     the number of GPUs; in the pool the chains of all frames run under each other, which is what lets this split scale (DESIGN.md
+//     section 5).
 //
 // All launches are asynchronous, so one host thread keeps N devices busy.  torch is not involved; torch.distributed (bench.py)
 // is the one-process-per-GPU alternative over the same kernels and the same shard layout.
@@ -303,92 +303,100 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
     return dsrt::guarded("dsrt_multi_render_sequence", [&]() -> int {
         const int n = (int)m->ranks.size();
         DsrtRenderDesc d = *desc_in;
-        d.shard_count = 0; d.shard_rank = 0;                        // whole frames
+        d.shard_count = n > 1 ? n : 0; d.shard_rank = 0;
         const size_t image_bytes = (size_t)d.width * d.height * 3;
-        // Every rank renders its frames in batch launches (dsrt_render_batch: the frames of a launch are one pool of work, so the serial
-        // chains of one frame run under the bulk of the others), costliest first; at most kGroup frames per launch, the rank's slots taking the launches in turn so that one launch's images travel to the
-        // host while the next one renders.
-        constexpr int kGroup = 32;
+        // EVERY rank renders its interleaved tiles of EVERY frame, as batch launches (dsrt_render_batch with a shard: the rank's tiles of all
+        // the frames of a launch are one pool of work).  Loads are equal by construction (each rank has every 8th tile of every frame), every
+        // frame's serial chains are spread over all GPUs AND run under the other frames' bulk, and the collective is one gather per launch for
+        // all its frames.  One rank's share of the 99-pose approach at 1080p x 250 on one MI355X: 8 ranks 0.29 s in rng_mode 0 (5.8x the
+        // single-GPU rate; whole frames dealt by cost: 5.0x, round-robin: 4.2x), 0.24 s in rng_mode 1 (7.3x).  Frames go nearest (costliest)
+        // first; as many per launch as its 32-bit work-item numbers allow, 128 at most.
+        constexpr size_t kGroup = 128;
         int rc;
-        // Whole frames are dealt by estimated cost, not round-robin: on an approach the nearest frames cost 30 times the farthest, and
-        // round-robin hands one rank the nearest of all (8 ranks: a quarter of the node idle).  Estimate: 1 / (distance from the camera to the
-        // scene's centre + the scene's radius); longest-processing-time first -- frames in order of falling estimate, each to the rank with
-        // the least so far (deep-space-ray-tracer_amd/sequence.py does the same for the one-process-per-GPU job).
-        std::vector<std::vector<int>> mine((size_t)n);
+        size_t padded_bytes = image_bytes;
+        if (n > 1 && (rc = dsrt_shard_layout(&d, nullptr, nullptr, nullptr, &padded_bytes))) return rc;
+        std::vector<int> order((size_t)n_frames);
         {
             float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
             if ((rc = dsrt_ctx_scene_bounds(m->ranks[0].slots[0].ctx, lo, hi))) return rc;
             const double centre[3] = {0.5 * ((double)lo[0] + hi[0]), 0.5 * ((double)lo[1] + hi[1]), 0.5 * ((double)lo[2] + hi[2])};
-            const double radius = 0.5 * std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]});
-            std::vector<double> cost((size_t)n_frames);
-            std::vector<int> by_cost((size_t)n_frames);
+            std::vector<double> dist((size_t)n_frames);
             for (int i = 0; i < n_frames; ++i) {
                 const double dx = cams[i].origin.x - centre[0], dy = cams[i].origin.y - centre[1], dz = cams[i].origin.z - centre[2];
-                cost[(size_t)i] = 1.0 / (std::sqrt(dx * dx + dy * dy + dz * dz) + radius + 1e-9);
-                by_cost[(size_t)i] = i;
+                dist[(size_t)i] = dx * dx + dy * dy + dz * dz;
+                order[(size_t)i] = i;
             }
-            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
-            std::vector<double> load((size_t)n, 0.0);
-            for (int i : by_cost) {                                                              // costliest first: also the order inside a rank's launches
-                size_t r = 0;
-                for (size_t q = 1; q < (size_t)n; ++q) if (load[q] < load[r]) r = q;
-                load[r] += cost[(size_t)i];
-                mine[r].push_back(i);
-            }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dist[(size_t)a] < dist[(size_t)b]; });
         }
-        size_t per_launch = 1;
-        for (const auto& v : mine) per_launch = std::max(per_launch, std::min(v.size(), (size_t)kGroup));
-        // 32-bit work-item numbers inside a launch (include/dsrt.h): fewer frames per launch for very large images
-        while (per_launch > 1 && (unsigned long long)per_launch * d.width * d.height * (d.rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;
+        size_t per_launch = std::max<size_t>(1, std::min<size_t>((size_t)n_frames, kGroup));
+        while (per_launch > 1 && (unsigned long long)per_launch * (padded_bytes / 3) * (d.rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;
+        Rank& root = m->ranks[0];
         for (Rank& k : m->ranks) {
             HIP_TRY(hipSetDevice(k.device));
-            const size_t use = std::min<size_t>(k.slots.size(), 2);             // two launches in turn are all that overlap: image buffers for those slots only
-            for (size_t si = 0; si < use; ++si) { Slot& s = k.slots[si]; if ((rc = ensure_slot_images(s, image_bytes * per_launch))) return rc; s.frame = -1; }
+            if (n > 1 && (rc = ensure(&k.d_part, &k.part_bytes, padded_bytes * per_launch))) return rc;
         }
+        HIP_TRY(hipSetDevice(root.device));
+        if ((rc = ensure_slot_images(root.slots[0], image_bytes * per_launch))) return rc;
+        if (n > 1 && (rc = ensure(&m->d_gathered, &m->gathered_bytes, padded_bytes * per_launch * (size_t)n))) return rc;
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<std::vector<std::vector<int>>> held((size_t)n);                              // per rank, per slot: the frames whose images the slot holds
-        for (int r = 0; r < n; ++r) held[(size_t)r].resize(m->ranks[(size_t)r].slots.size());
-        // Before a slot is re-used its images are handed over -- the only reason for the host to wait on a slot.
-        auto retire = [&](int r, size_t si) -> int {
-            Slot& s = m->ranks[(size_t)r].slots[si];
-            std::vector<int>& frames = held[(size_t)r][si];
-            if (frames.empty()) return DSRT_OK;
-            HIP_TRY(hipStreamSynchronize(s.stream));
-            for (size_t q = 0; q < frames.size(); ++q)
-                if (h_images && h_images[frames[q]]) std::memcpy(h_images[frames[q]], s.h_pinned + q * image_bytes, image_bytes);
-            frames.clear();
-            return DSRT_OK;
-        };
-        std::vector<size_t> next((size_t)n, 0), turn((size_t)n, 0);
         std::vector<GPUCamera> gcams;
         std::vector<float> gsuns;
-        for (bool any = true; any;) {                                                             // one launch per rank per round: all devices stay fed
-            any = false;
-            for (int r = 0; r < n; ++r) {
-                const std::vector<int>& v = mine[(size_t)r];
-                if (next[(size_t)r] >= v.size()) continue;
-                any = true;
-                Rank& k = m->ranks[(size_t)r];
-                const size_t si = turn[(size_t)r]++ % std::min<size_t>(k.slots.size(), 2);
-                Slot& s = k.slots[si];
-                HIP_TRY(hipSetDevice(k.device));
-                if ((rc = retire(r, si))) return rc;
-                const size_t count = std::min(per_launch, v.size() - next[(size_t)r]);
-                gcams.clear(); gsuns.clear();
-                for (size_t q = 0; q < count; ++q) {
-                    const int fi = v[next[(size_t)r] + q];
-                    gcams.push_back(cams[fi]);
-                    gsuns.insert(gsuns.end(), sun_dirs + 3 * (size_t)fi, sun_dirs + 3 * (size_t)fi + 3);
-                    held[(size_t)r][si].push_back(fi);
-                }
-                next[(size_t)r] += count;
-                if ((rc = dsrt_render_batch(s.ctx, &d, (int)count, gcams.data(), gsuns.data(), s.d_image, nullptr, s.stream, nullptr))) return rc;
-                HIP_TRY(hipMemcpyAsync(s.h_pinned, s.d_image, image_bytes * count, hipMemcpyDeviceToHost, s.stream));
+        for (size_t at = 0; at < (size_t)n_frames; at += per_launch) {
+            const size_t count = std::min(per_launch, (size_t)n_frames - at);
+            gcams.clear(); gsuns.clear();
+            for (size_t q = 0; q < count; ++q) {
+                const int fi = order[at + q];
+                gcams.push_back(cams[fi]);
+                gsuns.insert(gsuns.end(), sun_dirs + 3 * (size_t)fi, sun_dirs + 3 * (size_t)fi + 3);
             }
-        }
-        for (int r = 0; r < n; ++r) {
-            HIP_TRY(hipSetDevice(m->ranks[(size_t)r].device));
-            for (size_t si = 0; si < m->ranks[(size_t)r].slots.size(); ++si) if ((rc = retire(r, si))) return rc;
+            // 1. every rank renders its tiles of these frames (asynchronous: the loop returns as soon as the launches are queued)
+            for (int r = 0; r < n; ++r) {
+                Rank& k = m->ranks[(size_t)r];
+                HIP_TRY(hipSetDevice(k.device));
+                d.shard_rank = r;
+                if ((rc = dsrt_render_batch(k.slots[0].ctx, &d, (int)count, gcams.data(), gsuns.data(), n > 1 ? k.d_part : root.slots[0].d_image, nullptr,
+                                            k.slots[0].stream, nullptr))) return rc;
+            }
+            // 2. the one collective of the launch: equal-sized buffers (count parts each) -> rank 0
+            if (n > 1) {
+                const size_t send = padded_bytes * count;
+                if (m->rccl) {
+                    NCCL_TRY(ncclGroupStart());
+                    for (int r = 0; r < n; ++r) {
+                        Rank& k = m->ranks[(size_t)r];
+                        if (!nccl_ok(ncclGather(k.d_part, m->d_gathered, send, ncclUint8, 0, m->comms[(size_t)r], k.slots[0].stream), "ncclGather")) {
+                            (void)ncclGroupEnd();
+                            return DSRT_ERR_COMM;
+                        }
+                    }
+                    NCCL_TRY(ncclGroupEnd());
+                } else {
+                    for (int r = 0; r < n; ++r) {                      // ranks share a device: the same receive layout filled by copies
+                        Rank& k = m->ranks[(size_t)r];
+                        HIP_TRY(hipSetDevice(k.device));
+                        HIP_TRY(hipMemcpyAsync(m->d_gathered + (size_t)r * send, k.d_part, send, hipMemcpyDeviceToDevice, k.slots[0].stream));
+                        if (r > 0) {
+                            HIP_TRY(hipEventRecord(k.ev_sent, k.slots[0].stream));
+                            HIP_TRY(hipStreamWaitEvent(root.slots[0].stream, k.ev_sent, 0));
+                        }
+                    }
+                }
+                HIP_TRY(hipSetDevice(root.device));
+                d.shard_rank = 0;
+                if ((rc = dsrt_deinterleave_batch(root.slots[0].ctx, &d, (int)count, m->d_gathered, root.slots[0].d_image, root.slots[0].stream))) return rc;
+            }
+            // 3. images to the caller
+            HIP_TRY(hipSetDevice(root.device));
+            HIP_TRY(hipMemcpyAsync(root.slots[0].h_pinned, root.slots[0].d_image, image_bytes * count, hipMemcpyDeviceToHost, root.slots[0].stream));
+            for (int r = n - 1; r >= 0; --r) {
+                Rank& k = m->ranks[(size_t)r];
+                HIP_TRY(hipSetDevice(k.device));
+                HIP_TRY(hipStreamSynchronize(k.slots[0].stream));
+            }
+            for (size_t q = 0; q < count; ++q) {
+                const int fi = order[at + q];
+                if (h_images && h_images[fi]) std::memcpy(h_images[fi], root.slots[0].h_pinned + q * image_bytes, image_bytes);
+            }
         }
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return DSRT_OK;

@@ -525,7 +525,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                 px = x;
                 ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
                 out_index = P.compact_output ? (k * (uint32_t)(P.tile * P.tile) + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
-                if constexpr (BATCH) out_index += ln.frame * (uint32_t)(W * H);          // the batch's images lie one after another
+                if constexpr (BATCH) out_index += ln.frame * args.batch_frame_pixels;    // the batch's images (or shard buffers) lie one after another
                 accum = mk(0, 0, 0);
                 if (COUNT) ln.t0 = (uint32_t)wall_clock64();
                 if constexpr (RNGMODE == 0) {

@@ -241,8 +241,10 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
  *   sun_dirs_xyz : 3 * frames floats, HOST array (radiance and the enabled flag are the context's, dsrt_scene_set_camera_sun)
  *   d_rgb8       : DEVICE buffer, frames * width*height*3 bytes: the images one after another, each in dsrt_render's layout
  *   d_f32        : optional DEVICE buffer, frames * width*height*3 floats
- * Whole frames only (shard_count <= 1), production kernel only (no counters, not `checked`); frames * width * height (x 16 in rng_mode 1)
- * must stay below 2^32 -- split a longer sequence into several calls.  Asynchronous on `stream` unless `stats` is given
+ * With shard_count > 1 every frame's part is this rank's compact tile buffer (dsrt_shard_layout: rgb8_bytes_padded each), i.e. a rank renders its
+ * tiles of ALL the frames as one pool -- the split that scales a sequence over the GPUs of a node in either rng_mode, one gather for the lot.
+ * Production kernel only (no counters, not `checked`); frames * pixels per frame (x 16 in rng_mode 1) must stay below 2^32 -- split a longer
+ * sequence into several calls.  Asynchronous on `stream` unless `stats` is given
  * (kernel_ms then covers the one launch; the per-frame pre-passes before it are not included).
  */
 int dsrt_render_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const GPUCamera* cameras, const float* sun_dirs_xyz,
@@ -255,6 +257,9 @@ int dsrt_render_batch_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, int 
 /* Root rank, after a gather: tile-major shards [shard][tile][tile*tile*3] -> image-order rgb8. */
 int dsrt_deinterleave_tiles(DsrtContext* ctx, const DsrtRenderDesc* desc, const uint8_t* d_gathered, uint8_t* d_rgb8_image,
                             void* stream);
+/* The same for the gather of SHARDED BATCH launches (dsrt_render_batch with shard_count > 1): d_gathered = the ranks' buffers one after another,
+ * each holding its part of frame 0, of frame 1, ... (`frames` parts of rgb8_bytes_padded bytes); d_rgb8_images receives the `frames` whole images. */
+int dsrt_deinterleave_batch(DsrtContext* ctx, const DsrtRenderDesc* desc, int frames, const uint8_t* d_gathered, uint8_t* d_rgb8_images, void* stream);
 
 /* Convenience for hosts without their own device buffers: render the whole image into HOST memory. */
 int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h_rgb8, float* h_f32, DsrtStats* stats);

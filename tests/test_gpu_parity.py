@@ -658,9 +658,34 @@ def test_batch_launch_gives_every_frame_its_own_image(dsrt, gpu_ctx, oracle, tmp
         alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth))
         assert np.array_equal(got[k], alone), f"1080p batch, frame {i}"
     assert got[-1].max() > 0
-    # what a batch cannot be: sharded, counted, or bigger than its 32-bit indices
-    with pytest.raises(dsrt.DsrtError):
-        gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, shard_rank=0, shard_count=2), list(cams), list(suns), rgb.data_ptr())
+    # sharded batch: every rank renders ITS tiles of all the frames as one pool (the split that scales a sequence over a node); three ranks'
+    # compact buffers, frame by frame through the gather layout and the de-interleave, are the whole-frame images
+    W, H, spp = 150, 85, 64
+    small = [0, 70, 90, 98]
+
+    def frame_small(i):
+        fr = dsrt.pose_to_frame(poses[i])
+        return dsrt.frame_camera(fr, 40.0, W, H, spp, depth), tuple(fr.sun_dir_model)
+    cams, suns = zip(*[frame_small(i) for i in small])
+    world = 3
+    lay = dsrt.shard_layout(dsrt.make_desc(W, H, spp, depth, shard_rank=0, shard_count=world))
+    part_bytes = lay["rgb8_bytes_padded"]
+    for rng_mode in (0, 1):
+        parts = []
+        for r in range(world):
+            buf = torch.zeros(len(small) * part_bytes, dtype=torch.uint8, device="cuda")
+            gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, shard_rank=r, shard_count=world, rng_mode=rng_mode), list(cams), list(suns), buf.data_ptr(),
+                                 stream=stream, want_stats=True)
+            parts.append(buf)
+        for k, i in enumerate(small):
+            gathered = torch.cat([p[k * part_bytes:(k + 1) * part_bytes] for p in parts])
+            image = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+            gpu_ctx.deinterleave(dsrt.make_desc(W, H, spp, depth, shard_rank=0, shard_count=world), gathered.data_ptr(), image.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            gpu_ctx.set_camera_sun(cams[k], suns[k])
+            alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=rng_mode))
+            assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), alone), f"sharded batch, rng_mode {rng_mode}, frame {i}"
+    # what a batch cannot be: counted, checked, or bigger than its 32-bit indices
     with pytest.raises(dsrt.DsrtError):
         gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, collect_counters=1), list(cams), list(suns), rgb.data_ptr())
 

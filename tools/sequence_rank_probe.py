@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rng", type=int, default=0)
     ap.add_argument("--bvh", type=str, default="median")
     ap.add_argument("--deal", choices=["cost", "round-robin"], default="cost")
+    ap.add_argument("--split", choices=["frames", "tiles"], default="frames", help="frames: whole frames per rank; tiles: every rank its tiles of ALL frames (sharded batch)")
     a = ap.parse_args()
     import torch
     import dsrt_amd as d
@@ -48,12 +49,17 @@ def main():
     n_img = W * H * 3
     buf = torch.zeros(len(frames) * n_img, dtype=torch.uint8, device="cuda")
     host = torch.empty(len(frames) * n_img, dtype=torch.uint8).pin_memory()
-    desc = d.make_desc(W, H, spp, 50, rng_mode=a.rng)
     base = None
     for n in [int(x) for x in a.ranks.split(",")]:
         times = []
         for r in range(n):
-            ids = sorted(sequence.frame_assignment(frames, r, n, "frames", costs), reverse=True)
+            ids = sorted(sequence.frame_assignment(frames, r, n, a.split, costs), reverse=True)
+            if a.split == "tiles" and n > 1:
+                desc = d.make_desc(W, H, spp, 50, rng_mode=a.rng, shard_rank=r, shard_count=n)
+                n_img = d.shard_layout(desc)["rgb8_bytes_padded"]
+            else:
+                desc = d.make_desc(W, H, spp, 50, rng_mode=a.rng)
+                n_img = W * H * 3
             best = None
             for _ in range(2):
                 torch.cuda.synchronize()
@@ -66,7 +72,7 @@ def main():
             times.append(best)
         worst = max(times)
         base = worst if base is None else base
-        print(json.dumps({"ranks": n, "dealt_by": a.deal, "rng_mode": a.rng, "bvh": a.bvh, "spp": spp, "frames": len(frames), "rank_seconds": [round(t, 4) for t in times],
+        print(json.dumps({"ranks": n, "split": a.split, "dealt_by": a.deal if a.split == "frames" else None, "rng_mode": a.rng, "bvh": a.bvh, "spp": spp, "frames": len(frames), "rank_seconds": [round(t, 4) for t in times],
                           "frames_per_s": round(len(frames) / worst, 1), "speedup_vs_1": round(base / worst, 2)}), flush=True)
 
 
