@@ -553,8 +553,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         const bool cull = (desc->tune[3] & 3) == 0;
         HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));                          // culled pixels are never written
         if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
-        if (ctx->batch_table.n < (size_t)frames) { int rc = ctx->batch_table.alloc((size_t)frames); if (rc) return rc; }
-        ctx->batch_host.assign((size_t)frames, BatchFrame{});
+        if (ctx->batch_table.n < 2 * (size_t)frames) { int rc = ctx->batch_table.alloc(2 * (size_t)frames); if (rc) return rc; }
+        ctx->batch_host.assign(2 * (size_t)frames, BatchFrame{});
         for (int i = 0; i < frames; ++i) {
             const GPUCamera& bc = batch->cameras[i];
             BatchFrame& e = ctx->batch_host[(size_t)i];
@@ -563,13 +563,37 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             std::memcpy(e.cam_origin, cam12, sizeof cam12);                                   // origin, llc, horizontal, vertical are contiguous
             e.sun_dir[0] = batch->sun_dirs[i].x; e.sun_dir[1] = batch->sun_dirs[i].y; e.sun_dir[2] = batch->sun_dirs[i].z;
             e.order_base = (uint32_t)(pre_stride * (size_t)i);
+            e.image_slot = (uint32_t)i;
+            ctx->batch_host[(size_t)frames + (size_t)i] = e;                                  // the frame's second entry (device_layout.h, BatchFrame)
         }
-        HIP_TRY(hipMemcpyAsync(ctx->batch_table.p, ctx->batch_host.data(), (size_t)frames * sizeof(BatchFrame), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ctx->batch_table.p, ctx->batch_host.data(), 2 * (size_t)frames * sizeof(BatchFrame), hipMemcpyHostToDevice, stream));
         HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, sched, (uint32_t)f.chunks, 0u, cull, stream,
                                   ctx->batch_table.p, (uint32_t)frames, (uint32_t)pre_stride));
+        // rng_mode 0 at enough samples for a pixel to be a long chain: every frame's heavy tiles re-sorted by measured cost, as for a single
+        // frame (the probe launch below in this function) -- one probe per frame, 6 ms each at 1080p, against a frame of a second
+        if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 256) {
+            if (ctx->probe_queue.n < 1024) { int rc = ctx->probe_queue.alloc(1024); if (rc) return rc; }
+            for (int i = 0; i < frames; ++i) {
+                RenderArgs pa = a;
+                std::memcpy(pa.frame.cam_origin, ctx->batch_host[(size_t)i].cam_origin, 12 * sizeof(float));
+                std::memcpy(pa.frame.sun_dir, ctx->batch_host[(size_t)i].sun_dir, 3 * sizeof(float));
+                pa.frame.spp = 4; pa.frame.chunks = 1; pa.frame.chunk_len = 4;
+                pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
+                pa.sched = sched + pre_stride * (size_t)i;
+                pa.frame.tile_order = ctx->tile_order.p + pre_stride * (size_t)i;
+                pa.tile_work = ctx->tile_work.p;
+                pa.probe_queue = ctx->probe_queue.p;
+                HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
+                HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
+                HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
+                HIP_TRY(launch_probe(pa, blocks, stream));
+                HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p + pre_stride * (size_t)i, ctx->tile_tmp.p, sched + pre_stride * (size_t)i, stream));
+            }
+            HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
+        }
         HIP_TRY(launch_batch_table(ctx->batch_table.p, sched, (uint32_t)pre_stride, (uint32_t)frames, (uint32_t)(t.tile * t.tile), desc->rng_mode, f.spp,
                                    f.light_chunk_len, ctx->ctrl.p + 2, stream));
-        a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = (uint32_t)frames;
+        a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = 2u * (uint32_t)frames;
         a.batch_frame_pixels = (uint32_t)(out_pixels / (size_t)frames);        // whole images, or the padded compact shard buffers, one after another
     } else
     if ((desc->tune[3] & 3) != 1 && t.mine > 0) {
@@ -581,8 +605,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         HIP_TRY(launch_tile_order(a.scene, a.frame, ctx->tile_cost.p, ctx->tile_order.p, sched, (uint32_t)f.chunks,
                                   (uint32_t)blocks * (uint32_t)threads_per_block, cull, stream));
         a.frame.tile_order = ctx->tile_order.p;
-        // Probe: the render kernel itself at kProbeSpp samples per pixel (reference stream, output discarded: the frame overwrites
-        // it) measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.5 % only when a pixel is a
+        // Probe: the render kernel itself at kProbeSpp samples per pixel (reference stream, nothing stored)
+        // measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.5 % only when a pixel is a
         // long chain; tune[3] bit 3 (value 8) switches it off.
         constexpr int kProbeSpp = 4;          // x every pixel of the heavy tiles: 7 ms at 1080p, near frame.  (1, 2, 4 or 8 samples order the tiles equally well.)
         // Its work items are tiny, so the probe has 64 queue words of its own (path_machine.h, ST_FETCH): on the frame's single queue word

@@ -83,8 +83,11 @@ struct FrameParams {
     const uint32_t* tile_order; // processing order of this shard's tiles (local tile numbers, costliest first); null = natural order
 };
 
-// One frame of a batch launch (dsrt_render_batch): what differs from frame to frame.  The first 15 floats are filled by the host, the
-// counts by dsrt_batch_table_kernel from what each frame's pre-pass left in its `sched` words.
+// One entry of a batch launch's table (dsrt_render_batch): a contiguous part of ONE frame's tile order, with what differs from frame to
+// frame.  Every frame has two entries -- the first eighth of its heavy tiles (its longest chains), and the rest -- and the table lists all
+// frames' first parts before all frames' second parts, so that every frame's longest chains start at the beginning of the launch.  Camera,
+// sun and image slot are filled by the host (the same in both entries of a frame), the counts by dsrt_batch_table_kernel from what each
+// frame's pre-pass left in its `sched` words.
 struct BatchFrame {
     float    cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3];     // contiguous: path_machine.h reads them as 12 floats
     float    sun_dir[3];
@@ -92,7 +95,8 @@ struct BatchFrame {
     uint32_t order_base;       // where this frame's tile order starts in RenderArgs::batch_order
     uint32_t n_heavy, n_live;  // tiles that see geometry / tiles not proven empty
     uint32_t slices, chunk_len; // rng_mode 1: work items per heavy pixel and their length
-    uint32_t pad[3];
+    uint32_t image_slot;       // which of the launch's output images this entry's pixels belong to
+    uint32_t pad[2];
 };
 static_assert(sizeof(BatchFrame) == 96, "BatchFrame is shared with the host as an array");
 
@@ -110,9 +114,9 @@ struct RenderArgs {
     uint32_t* probe_queue;     // probe launch only: 64 queue words, 64 bytes apart (path_machine.h, ST_FETCH)
     int       hot_shift;       // rng_mode 0: 0 = off; s > 0: pixels of the first n_heavy >> (s - 1) tiles of the order raise their wave's issue priority
     int       hot_graded;      //   1 = three levels (that share, a quarter and a sixteenth of it), 0 = one level
-    const BatchFrame* batch;   // batch launch only: one entry per frame
+    const BatchFrame* batch;   // batch launch only: the table, batch_frames entries (two per frame)
     const uint32_t* batch_order; //   the frames' tile orders, BatchFrame::order_base apart
-    uint32_t  batch_frames, batch_frame_pixels;   // frames in the launch; output pixels per frame (W*H, or a shard's padded tile buffer)
+    uint32_t  batch_frames, batch_frame_pixels;   // table entries in the launch; output pixels per frame (W*H, or a shard's padded tile buffer)
     uint32_t* tile_work;       // probe launch only (null otherwise): rays traced per local tile, the measured cost the order is refined by
     uint64_t* counters;        // kNumCounters entries (counting build only)
     uint32_t* flags;           // checked-mode status word

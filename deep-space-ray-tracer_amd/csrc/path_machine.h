@@ -55,7 +55,7 @@ struct Lane {
     int sample_end = 0;                          // rng_mode 1: this work item covers samples [.., sample_end) of the pixel
     uint32_t chunk = 0;                          // rng_mode 1: which slice of the pixel's samples
     uint32_t aux = 0;                            // lane number inside the wave + helper / await bits (see above)
-    uint32_t frame = 0;                          // batch launches (dsrt_render_batch): which frame of the batch this lane's pixel belongs to
+    uint32_t frame = 0;                          // batch launches (dsrt_render_batch): the table entry (camera, sun) this lane's pixel belongs to
     uint32_t t0 = 0;                             // counting build: wall clock (100 MHz, low 32 bits) when this lane fetched its current work item
     F3 accum = {0, 0, 0}, thr = {1, 1, 1}, L = {0, 0, 0};
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
@@ -413,10 +413,12 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             col = mk(dsrt_powf(col.x, P.inv_gamma), dsrt_powf(col.y, P.inv_gamma), dsrt_powf(col.z, P.inv_gamma));
             col = clamp01(col);
             const size_t o = (size_t)out_index * 3;
-            args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
-            args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
-            args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
-            if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
+            if constexpr (!PROBE) {                             // (the probe launch measures, it has no image: in a batch its frame is not even the buffer's)
+                args.out_rgb8[o + 0] = (unsigned char)(255.99f * col.x);
+                args.out_rgb8[o + 1] = (unsigned char)(255.99f * col.y);
+                args.out_rgb8[o + 2] = (unsigned char)(255.99f * col.z);
+                if (args.out_f32) { args.out_f32[o + 0] = col.x; args.out_f32[o + 1] = col.y; args.out_f32[o + 2] = col.z; }
+            }
             if (COUNT && (args.steal & 8) && args.out_f32) {
                 // timing image (counting build, tune[3] bit 27; tools/chain_timeline.py): instead of the colour, the float image receives as
                 // bit patterns when this pixel's chain of samples was fetched, when it ended, and which wave ran it
@@ -525,7 +527,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                 px = x;
                 ky = H - 1 - row;                               // the kernel's y: 0 at the bottom (:984, :1027)
                 out_index = P.compact_output ? (k * (uint32_t)(P.tile * P.tile) + in_y * (uint32_t)P.tile + in_x) : ((uint32_t)row * (uint32_t)W + (uint32_t)x);
-                if constexpr (BATCH) out_index += ln.frame * args.batch_frame_pixels;    // the batch's images (or shard buffers) lie one after another
+                if constexpr (BATCH) out_index += bf->image_slot * args.batch_frame_pixels;     // the batch's images (or shard buffers) lie one after another
                 accum = mk(0, 0, 0);
                 if (COUNT) ln.t0 = (uint32_t)wall_clock64();
                 if constexpr (RNGMODE == 0) {

@@ -268,19 +268,24 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
     render_body<8, false, false, true, RNGMODE, false, true>(args);
 }
 
-// Fills the count fields of the batch table from the sched words every frame's pre-pass wrote (sched_stride apart), and the running item total.
+// Fills the count fields of the batch table (entries f and frames + f belong to frame f) from the sched words every frame's pre-pass
+// wrote (sched_stride apart), and the running item totals.
 __global__ void dsrt_batch_table_kernel(BatchFrame* __restrict__ table, const uint32_t* __restrict__ sched, uint32_t sched_stride, uint32_t frames,
                                         uint32_t tt, int rng_mode, int spp, int light_chunk_len, uint32_t* __restrict__ total_items) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     unsigned long long acc = 0;
-    for (uint32_t f = 0; f < frames; ++f) {
+    const uint32_t light_slices = rng_mode == 1 ? (uint32_t)((spp + light_chunk_len - 1) / light_chunk_len) : 1u;
+    for (uint32_t e = 0; e < 2u * frames; ++e) {
+        const uint32_t f = e < frames ? e : e - frames;
         const uint32_t* s = sched + (size_t)f * sched_stride;
-        BatchFrame& e = table[f];
-        e.n_heavy = s[0]; e.n_live = s[1];
-        e.slices = rng_mode == 1 ? s[3] : 1u; e.chunk_len = rng_mode == 1 ? s[4] : (uint32_t)spp;
-        const uint32_t light_slices = rng_mode == 1 ? (uint32_t)((spp + light_chunk_len - 1) / light_chunk_len) : 1u;
-        acc += (unsigned long long)e.n_heavy * tt * e.slices + (unsigned long long)(e.n_live - e.n_heavy) * tt * light_slices;
-        e.item_end = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;           // (the host bounds frames x pixels x 64 below 2^32)
+        const uint32_t n_heavy = s[0], n_live = s[1];
+        const uint32_t top = n_heavy ? (n_heavy >> 3 ? n_heavy >> 3 : 1u) : 0u;           // the first eighth of the heavy tiles, at least one
+        BatchFrame& b = table[e];
+        if (e < frames) { b.n_heavy = top; b.n_live = top; }
+        else { b.n_heavy = n_heavy - top; b.n_live = n_live - top; b.order_base += top; }
+        b.slices = rng_mode == 1 ? s[3] : 1u; b.chunk_len = rng_mode == 1 ? s[4] : (uint32_t)spp;
+        acc += (unsigned long long)b.n_heavy * tt * b.slices + (unsigned long long)(b.n_live - b.n_heavy) * tt * light_slices;
+        b.item_end = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;           // (the host bounds frames x pixels x 16 below 2^32)
     }
     *total_items = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;
 }
