@@ -243,6 +243,8 @@ int dsrt_render(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_rgb8, f
  *   d_f32        : optional DEVICE buffer, frames * width*height*3 floats
  * With shard_count > 1 every frame's part is this rank's compact tile buffer (dsrt_shard_layout: rgb8_bytes_padded each), i.e. a rank renders its
  * tiles of ALL the frames as one pool -- the split that scales a sequence over the GPUs of a node in either rng_mode, one gather for the lot.
+ * Work is handed out frame after frame in the order given (put the costliest -- nearest -- frames first), every frame's first eighth of heavy tiles
+ * before any frame's remainder; in rng_mode 0 at 256 samples and more each frame's tiles are first re-sorted by a probe launch, as in dsrt_render.
  * Production kernel only (no counters, not `checked`); frames * pixels per frame (x 16 in rng_mode 1) must stay below 2^32 -- split a longer
  * sequence into several calls.  Asynchronous on `stream` unless `stats` is given
  * (kernel_ms then covers the one launch; the per-frame pre-passes before it are not included).
