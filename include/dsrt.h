@@ -32,7 +32,7 @@ extern "C" {
 #define DSRT_ERR_COMM        -9   /* an RCCL call failed                                         */
 
 const char* dsrt_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature or struct change; 3 = round 2: DsrtStats grew, dsrt_render_batch, dsrt_multi_*). */
 int dsrt_abi_version(void);
 
 /* ===================================================================================== */
