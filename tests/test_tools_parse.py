@@ -1,0 +1,28 @@
+"""The development aids under tools/ and the entry points at the repo root are not exercised by the suites on a CPU-only machine: at least
+every one of them has to parse, and bench.py's command line has to build."""
+import ast
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_tools_and_entry_points_parse():
+    files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, n) for n in ("bench.py", "__graft_entry__.py")]
+    assert len(files) >= 10
+    for path in files:
+        ast.parse(open(path).read(), filename=path)
+
+
+def test_bench_command_line_builds():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--sequence", "--batch", "--split", "--deal", "--single-process"):
+        assert flag in out.stdout, flag
+
+
+def test_shell_tools_are_syntactically_valid():
+    for path in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh"))):
+        assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0, path
