@@ -559,11 +559,18 @@ def main():
     # stays one launch per step, each waited for.
     batched = None
     if shard:
-        try:
-            nb = max(2, args.steps)
-            pbytes = lay["rgb8_bytes_padded"]
-            bbuf = torch.zeros(nb * pbytes, dtype=torch.uint8, device=dev)
+        nb = max(2, args.steps)
+        pbytes = lay["rgb8_bytes_padded"]
+        bbuf = bimg = None
+        try:                                                          # (allocation is the one step that can fail on one rank only: agree on it
+            bbuf = torch.zeros(nb * pbytes, dtype=torch.uint8, device=dev)        #  before anybody enters a collective)
             bimg = torch.zeros(nb * W * H * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
+            mine_ok = 1.0
+        except Exception:  # noqa: BLE001
+            mine_ok = 0.0
+        agreed = torch.tensor([mine_ok], dtype=torch.float64, device=dev)
+        all_reduce(agreed, dist.ReduceOp.MIN)
+        if float(agreed.item()) == 1.0:
             sun = tuple(fr.sun_dir_model)
 
             def batch_step():
@@ -583,9 +590,9 @@ def main():
             per = float(tb.item()) / nb
             batched = {"frames_in_the_launch": nb, "ms_per_frame": per * 1e3, "Msamples/s": W * H * spp / per / 1e6,
                        "every_image_equals_the_step_image": bool(all(torch.equal(bimg[k * W * H * 3:(k + 1) * W * H * 3], image) for k in range(nb))) if rank == 0 else None}
-            del bbuf, bimg
-        except Exception as e:  # noqa: BLE001 -- an extra never stops the bench
-            batched = {"error": str(e)[:200]}
+        else:
+            batched = {"error": "a rank could not allocate the batch buffers"}
+        del bbuf, bimg
     # N > 1: the same sharded step with rng_mode 1 (a Philox sub-sequence per sample: the mode whose work units are samples, not
     # 1000-sample pixel chains, and therefore the one that can scale).  Reported beside the headline, never instead of it.
     mode1 = None
