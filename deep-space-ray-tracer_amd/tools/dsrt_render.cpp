@@ -26,7 +26,7 @@ static int fail(const char* what) {
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
     int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0;
-    bool sah = false, png = false, strict_textures = false;
+    bool sah = false, lbvh = false, png = false, strict_textures = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* {
@@ -43,12 +43,12 @@ int main(int argc, char** argv) {
         else if (a == "--frame") first = std::atoi(next("--frame"));
         else if (a == "--frames") count = std::atoi(next("--frames"));
         else if (a == "--fast") { sah = true; rng_mode = 1; }      // non-parity fast mode: SAH tree + Philox stream per sample (include/dsrt.h)
-        else if (a == "--bvh") sah = std::string(next("--bvh")) == "sah";
+        else if (a == "--bvh") { const std::string k = next("--bvh"); sah = k == "sah"; lbvh = k == "lbvh"; }      // lbvh: built on the GPU (milliseconds), non-parity like sah
         else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
         else if (a == "--strict-textures") strict_textures = true;  // refuse a mesh whose texture maps this library cannot decode (include/dsrt.h)
         else if (a == "--png") png = true;                          // frames as PNG instead of PPM (the reference converts with ImageMagick)
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah] [--rng-mode 0|1] [--fast] [--png] [--strict-textures]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah|lbvh] [--rng-mode 0|1] [--fast] [--png] [--strict-textures]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -82,7 +82,12 @@ int main(int argc, char** argv) {
             if (strict_textures) return 3;
         }
     }
-    if ((sah ? dsrt_host_scene_build_bvh_sah(hs) : dsrt_host_scene_build_bvh(hs)) != DSRT_OK) return fail("building the BVH");
+    {
+        float build_ms = 0.0f, total_ms = 0.0f;
+        const int rc = lbvh ? dsrt_host_scene_build_bvh_gpu(hs, 0, &build_ms, &total_ms) : (sah ? dsrt_host_scene_build_bvh_sah(hs) : dsrt_host_scene_build_bvh(hs));
+        if (rc != DSRT_OK) return fail("building the BVH");
+        if (lbvh) std::printf("BVH built on the GPU: %.2f ms of kernels, %.2f ms with upload and copy-back\n", build_ms, total_ms);
+    }
     GPUScene scene;
     if (dsrt_host_scene_view(hs, &scene) != DSRT_OK) return fail("viewing the scene");
     std::printf("mesh: %d triangles, %d BVH nodes, %d materials\n", scene.num_triangles, scene.num_bvh_nodes, scene.num_materials);

@@ -428,6 +428,12 @@ def test_cli_renders_pose_frames_like_the_library(dsrt, oracle, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     fast = np.frombuffer((out3 / "frame_0098.ppm").read_bytes()[len(head):], np.uint8).reshape(H, W, 3)
     assert abs(fast.astype(float).mean() - want.astype(float).mean()) < 3.0
+    # the tree built on the GPU: same flow, a picture of the same level
+    out4 = tmp_path / "lbvh"
+    r = subprocess.run(common + ["--output_dir", str(out4), "--bvh", "lbvh"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BVH built on the GPU" in r.stdout, r.stdout + r.stderr
+    gpu_tree = np.frombuffer((out4 / "frame_0098.ppm").read_bytes()[len(head):], np.uint8).reshape(H, W, 3)
+    assert abs(gpu_tree.astype(float).mean() - want.astype(float).mean()) < 3.0
     # usage errors
     assert subprocess.run([exe], capture_output=True).returncode == 2
 
