@@ -691,6 +691,22 @@ def test_batch_launch_gives_every_frame_its_own_image(dsrt, gpu_ctx, oracle, tmp
             gpu_ctx.set_camera_sun(cams[k], suns[k])
             alone, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=rng_mode))
             assert np.array_equal(image.cpu().numpy().reshape(H, W, 3), alone), f"sharded batch, rng_mode {rng_mode}, frame {i}"
+    # other kinds of scene and tile: spheres + lights (no BVH culling), textures and mixed materials, 16-pixel tiles; three views each in one
+    # launch, every view against the oracle
+    for name in ("lights", "textured", "mixed", "c1_spheres"):
+        world, cam_args, spp = CASES[name]
+        hs2 = load_world(dsrt, world)
+        W, H, depth2 = cam_args[3], cam_args[4], cam_args[5]
+        views = [dsrt.camera_look_at(tuple(np.float64(cam_args[0]) * k), cam_args[1], cam_args[2], W, H, spp, depth2) for k in (1.0, 1.35, 0.8)]
+        gpu_ctx.upload(hs2.view(views[0], SUN))
+        rgb = torch.zeros(len(views) * H * W * 3, dtype=torch.uint8, device="cuda")
+        f32 = torch.zeros(len(views) * H * W * 3, dtype=torch.float32, device="cuda")
+        gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth2, tile_size=16), views, [SUN] * len(views), rgb.data_ptr(), f32.data_ptr(), stream=stream, want_stats=True)
+        got = rgb.cpu().numpy().reshape(len(views), H, W, 3)
+        got32 = f32.cpu().numpy().reshape(len(views), H, W, 3)
+        for k, v in enumerate(views):
+            want, want32, _ = oracle.render(hs2.view(v, SUN), W, H)
+            assert np.array_equal(got[k], want) and np.array_equal(got32[k].view(np.uint32), want32.view(np.uint32)), (name, k)
     # what a batch cannot be: counted, checked, or bigger than its 32-bit indices
     with pytest.raises(dsrt.DsrtError):
         gpu_ctx.render_batch(dsrt.make_desc(W, H, spp, depth, collect_counters=1), list(cams), list(suns), rgb.data_ptr())
