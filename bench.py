@@ -272,7 +272,8 @@ def run_sequence_batched(args, d, ctx, frames, mine, frame_scene, W, H, spp, dep
     import torch
     import torch.distributed as dist
     sharded = tiles and world > 1
-    desc = d.make_desc(W, H, spp, depth, rng_mode=args.rng_mode, tune=(0, 0, 0, args.tune3), shard_rank=rank if sharded else 0, shard_count=world if sharded else 0)
+    desc = d.make_desc(W, H, spp, depth, rng_mode=args.rng_mode, tune=tuple(int(v) for v in args.tune012.split(":")) + (args.tune3,), shard_rank=rank if sharded else 0,
+                       shard_count=world if sharded else 0)
     part = d.shard_layout(desc)["rgb8_bytes_padded"] if sharded else W * H * 3
     B = max(1, min(args.batch, ((1 << 32) - 1) // ((part // 3) * (16 if args.rng_mode == 1 else 1))))      # 32-bit work-item numbers inside a launch (include/dsrt.h)
     ids = sorted(mine, reverse=True)
@@ -367,6 +368,7 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="N > 1: drive all GPUs from this process through dsrt_multi_* (library-side RCCL gather)")
     ap.add_argument("--deal", choices=["cost", "round-robin"], default="cost", help="--sequence on N GPUs, --split frames: how whole frames are dealt to ranks")
     ap.add_argument("--batch", type=int, default=99, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
+    ap.add_argument("--tune012", type=str, default="0:0:0", help="--sequence: DsrtRenderDesc.tune[0..2] = min_walk_iters:advance_budget:leaf_ratio4 (development aid)")
     ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
