@@ -360,7 +360,8 @@ def main():
     ap.add_argument("--sequence", action="store_true", help="config 5: render every pose of the file once (default 250 spp) and report frames/s")
     ap.add_argument("--split", choices=["frames", "tiles"], default="tiles",
                     help="--sequence on N > 1 GPUs: tiles = every rank renders its interleaved tiles of EVERY pose as one pool, one gather per launch (default: "
-                         "equal loads, 5.8x at 8 ranks in rng_mode 0); frames = whole poses dealt to ranks by estimated cost, no collective (5.0x)")
+                         "equal loads; projected from single-GPU shard probes, never yet measured on N GPUs: 5.8x at 8 ranks in rng_mode 0); frames = whole poses dealt to "
+                         "ranks by estimated cost, no collective (projected 5.0x)")
     ap.add_argument("--rng-mode", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=16, help="--sequence: frames in flight at once per GPU (separate streams; contexts share the scene)")
     ap.add_argument("--bvh", choices=["median", "sah", "lbvh"], default="median",
@@ -369,7 +370,7 @@ def main():
     ap.add_argument("--deal", choices=["cost", "round-robin"], default="cost", help="--sequence on N GPUs, --split frames: how whole frames are dealt to ranks")
     ap.add_argument("--batch", type=int, default=99, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
     ap.add_argument("--tune012", type=str, default="0:0:0", help="--sequence: DsrtRenderDesc.tune[0..2] = min_walk_iters:advance_budget:leaf_ratio4 (development aid)")
-    ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3] scheduling flags (development aid; include/dsrt.h)")
+    ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3], the DSRT_TUNE_* switches of include/dsrt.h (development switches: env DSRT_EXPERIMENT)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 

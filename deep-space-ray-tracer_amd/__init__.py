@@ -208,6 +208,16 @@ def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_
             "ms": ms.value, "records": rec.value, "Grecords_per_s": rec.value / ms.value / 1e6}
 
 
+def microbench_valu(kind=0, waves_per_simd=4, iters=20000, lane_mask=(1 << 64) - 1, device=0):
+    """VALU issue calibration (include/dsrt.h): {"ms", "wave_instructions", "cycles_per_instruction_per_simd", ...}."""
+    ms, n, cyc = C.c_float(), C.c_double(), C.c_double()
+    _check(lib.dsrt_microbench_valu(int(device), int(kind), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(cyc)),
+           "dsrt_microbench_valu")
+    return {"kind": ("v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cndmask_b32", "v_max3_f32")[kind], "waves_per_simd": waves_per_simd, "iters": iters,
+            "lanes": bin(lane_mask).count("1"), "lane_mask": hex(lane_mask), "ms": ms.value, "wave_instructions": n.value,
+            "G_wave_instructions_per_s": n.value / ms.value / 1e6, "cycles_per_instruction_per_simd": cyc.value}
+
+
 def stats_dict(st):
     return {name: getattr(st, name) for name, _ in DsrtStats._fields_}
 
@@ -297,7 +307,8 @@ class Context:
 
 
 class Multi:
-    """All GPUs of a node from one process (DsrtMulti): tile-sharded frames with one RCCL gather, or whole frames dealt round-robin."""
+    """All GPUs of a node from one process (DsrtMulti): a frame, or every frame of a sequence, sharded by interleaved screen tiles; one RCCL gather
+    per frame (render_frame) or per batch launch (render_sequence)."""
 
     def __init__(self, devices, frames_in_flight=1):
         devs = (C.c_int * len(devices))(*[int(x) for x in devices])
@@ -329,7 +340,7 @@ class Multi:
         return img, list(ms), sec.value
 
     def render_sequence(self, desc, cameras, sun_dirs, want_images=True):
-        """Frame i whole on rank i mod N.  -> (list of images or None, wall seconds)"""
+        """Every rank renders its tiles of every frame as sharded batch launches (dsrt_multi_render_sequence).  -> (list of images or None, wall seconds)"""
         n = len(cameras)
         cams = (GPUCamera * n)(*cameras)
         suns = (C.c_float * (3 * n))(*[float(v) for s3 in sun_dirs for v in s3])

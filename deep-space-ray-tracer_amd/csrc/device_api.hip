@@ -45,8 +45,13 @@ namespace {
 
 // Frames in flight on separate streams (dsrt_ctx_clone, dsrt_multi_render_sequence) only overlap on the device if each stream
 // gets a hardware queue of its own; the HIP runtime maps streams onto 4 unless told otherwise BEFORE it initialises.  The
-// library asks for 16 when it is loaded, unless the host has set the variable itself.  (No effect if HIP is already up.)
-struct HwQueuesDefault { HwQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); } } g_hw_queues_default;
+// library asks for 16 in its first dsrt_device_count / dsrt_ctx_create call -- documented there in include/dsrt.h; not at load time, so
+// that loading the library changes nothing in the host process -- unless the host has set the variable itself.  (No effect if HIP is
+// already up.)
+void hw_queues_default() {
+    static std::once_flag once;
+    std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+}
 
 bool hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
@@ -299,11 +304,27 @@ bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
     return true;
 }
 
+// Development switches.  They are NOT part of the ABI (include/dsrt.h refuses unknown bits of DsrtRenderDesc.tune[3]); the A/B tools
+// under tools/ set them through the environment variable DSRT_EXPERIMENT (an integer in C syntax, read at every render call):
+//   64           8 probe samples per pixel instead of 4
+//   bits 8-19    rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass)
+//   bits 20-22   grid = resident set >> n (frames that overlap on separate streams)
+//   bit 27       counting build of rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as bit patterns,
+//                100 MHz ticks, instead of the colour (tools/chain_timeline.py)
+//   bits 28-29   rng_mode 1: least samples per work item of a background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512
+//   bit 31       rng_mode 1: background pixels one item each
+// None of them changes a pixel either (tests/test_gpu_parity.py runs the render under several of them against the oracle).
+uint32_t experiment_word() {
+    const char* e = std::getenv("DSRT_EXPERIMENT");
+    return e && *e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
+}
+
 }  // namespace
 
 extern "C" {
 
 int dsrt_device_count(void) {
+    hw_queues_default();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -312,6 +333,7 @@ int dsrt_device_count(void) {
 int dsrt_ctx_create(int device, DsrtContext** out) {
     if (!out) { set_error("dsrt_ctx_create: null out"); return DSRT_ERR_INVALID; }
     *out = nullptr;
+    hw_queues_default();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return DSRT_ERR_NO_DEVICE; }
     if (device < 0 || device >= n) { set_error("device index out of range"); return DSRT_ERR_INVALID; }
@@ -420,6 +442,9 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
     if (!ctx->scene || !ctx->scene->valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
     if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
+    if (desc->tune[3] & ~DSRT_TUNE_FLAG_MASK) { set_error("dsrt_render: tune[3] has bits set that this ABI version does not define (DSRT_TUNE_* in include/dsrt.h)"); return DSRT_ERR_INVALID; }
+    const uint32_t flags = (uint32_t)desc->tune[3];
+    const uint32_t xp = experiment_word();
     Tiling t;
     if (!make_tiling(*desc, t)) { set_error("dsrt_render: bad size, tile or shard"); return DSRT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -432,10 +457,12 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.scene = sc.view;
     FrameParams& f = a.frame;
     const GPUCamera& c = ctx->camera;
-    f.cam_origin[0] = c.origin.x; f.cam_origin[1] = c.origin.y; f.cam_origin[2] = c.origin.z;
-    f.cam_llc[0] = c.lower_left_corner.x; f.cam_llc[1] = c.lower_left_corner.y; f.cam_llc[2] = c.lower_left_corner.z;
-    f.cam_horizontal[0] = c.horizontal.x; f.cam_horizontal[1] = c.horizontal.y; f.cam_horizontal[2] = c.horizontal.z;
-    f.cam_vertical[0] = c.vertical.x; f.cam_vertical[1] = c.vertical.y; f.cam_vertical[2] = c.vertical.z;
+    {
+        const float cam12[12] = {c.origin.x, c.origin.y, c.origin.z, c.lower_left_corner.x, c.lower_left_corner.y, c.lower_left_corner.z,
+                                 c.horizontal.x, c.horizontal.y, c.horizontal.z, c.vertical.x, c.vertical.y, c.vertical.z};
+        static_assert(sizeof cam12 == sizeof f.cam, "camera block");
+        std::memcpy(f.cam, cam12, sizeof cam12);
+    }
     f.sun_dir[0] = ctx->sun_dir.x; f.sun_dir[1] = ctx->sun_dir.y; f.sun_dir[2] = ctx->sun_dir.z;
     f.sun_radiance[0] = ctx->sun_radiance.x; f.sun_radiance[1] = ctx->sun_radiance.y; f.sun_radiance[2] = ctx->sun_radiance.z;
     f.sun_enabled = ctx->sun_enabled;
@@ -472,7 +499,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         // 1091 / 1076 / 1063 / 1050 / 1047 (profiles/r02/README.md).  An item's integer sums are 32-bit in units of 2^-20: at most 4095
         // samples per item, so with more samples than that every pixel is sliced, whatever its tile sees.
         f.chunk_len = (f.spp + 7) / 8;
-        if ((desc->tune[3] >> 8) & 0xFFF) f.chunk_len = (f.spp + ((desc->tune[3] >> 8) & 0xFFF) - 1) / ((desc->tune[3] >> 8) & 0xFFF);   // experiments: slices per pixel
+        if ((xp >> 8) & 0xFFFu) f.chunk_len = (f.spp + (int)((xp >> 8) & 0xFFFu) - 1) / (int)((xp >> 8) & 0xFFFu);   // experiment: slices per pixel
         if (f.chunk_len < 1) f.chunk_len = 1;
         if (f.chunk_len > 4095) f.chunk_len = 4095;
         f.chunks = (f.spp + f.chunk_len - 1) / f.chunk_len;
@@ -481,9 +508,9 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         // 70 60 -> 43 ms); cut as finely as the heavy pixels, their three 64-bit atomics per item cost the 250-spp sequence, whose frames
         // overlap and have no tail to lose, a fifth of its frame rate (47 -> 38 frames/s).
         {
-            const int code = (desc->tune[3] >> 28) & 3;                                       // experiments
+            const int code = (int)((xp >> 28) & 3u);                                          // experiment
             const int kLightLen = code == 0 ? 128 : (code == 1 ? 64 : (code == 2 ? 256 : 512));
-            f.light_chunk_len = ((uint32_t)desc->tune[3] & 0x80000000u) ? f.spp : std::max(f.chunk_len, kLightLen);
+            f.light_chunk_len = (xp & 0x80000000u) ? f.spp : std::max(f.chunk_len, kLightLen);
             if (f.light_chunk_len > 4095) f.light_chunk_len = 4095;
         }
         if (desc->width > 65535 || desc->height > 65535) { set_error("dsrt_render: rng_mode 1 hands samples between lanes with 16-bit pixel coordinates (width, height <= 65535)"); return DSRT_ERR_INVALID; }
@@ -507,7 +534,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     const int threads_per_block = 64 * kernel_waves_per_block();
     const int resident_blocks = ctx->num_cus * 4;                         // 4 waves per SIMD = 4 workgroups of 4 waves per CU (render_kernel.hip)
     int blocks = resident_blocks;                                         // persistent: exactly the resident set
-    if ((desc->tune[3] >> 20) & 7) blocks = std::max(1, resident_blocks >> ((desc->tune[3] >> 20) & 7));     // experiment: a fraction of it (frames that overlap)
+    if ((xp >> 20) & 7u) blocks = std::max(1, resident_blocks >> ((xp >> 20) & 7u));     // experiment: a fraction of it (frames that overlap)
     {
         const long long needed = ((long long)f.total_items + threads_per_block - 1) / threads_per_block;
         if (needed < blocks && !batch) blocks = (int)(needed > 0 ? needed : 1);
@@ -524,18 +551,16 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
-    a.helpers = (desc->tune[3] & 4) ? 0 : 1;
-    a.steal = ((desc->tune[3] & 16) ? 0 : 1) | ((desc->tune[3] & (1 << 27)) ? 8 : 0);      // (8: timing image, counting build)
+    a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
+    a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | ((xp & (1u << 27)) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
     // Interleaved medians, 1080p x 1000: near frame 1117 -> 1108 ms, frame 95 801 -> 785 ms.  Finer grades (the top quarter and sixteenth of
-    // the order above the rest) move nothing consistently: near frame 1103, frame 95 801; one of 8 shares 543 ms with every setting -- a
-    // long chain is bound by its own latency, not by its neighbours (profiles/r02/ab_issue_priority.jsonl).  Field 7 = off, 2-6 = experiments.
-    { const int f = (desc->tune[3] >> 23) & 7; a.hot_shift = f == 0 ? 1 : (f == 7 ? 0 : f); }
-    a.hot_graded = (desc->tune[3] >> 26) & 1;
+    // the order above the rest) were tried in round 2 and moved nothing consistently (profiles/r02/ab_issue_priority.jsonl); they are gone.
+    a.hot = (flags & DSRT_TUNE_NO_PRIORITY) ? 0 : 1;
 
     HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
     // Pre-pass for this camera: costliest-first tile order (scheduling only) and removal of tiles that are provably empty (exact:
-    // see dsrt_tile_cost_kernel).  tune[3] == 1 switches both off, == 2 keeps the order but culls nothing; counting builds never
+    // see dsrt_tile_cost_kernel).  DSRT_TUNE_NATURAL_ORDER switches both off, DSRT_TUNE_NO_CULLING keeps the order but culls nothing; counting builds never
     // cull, so that their counters cover every sample.  The words 32 and 48 entries past the cost array receive the number of
     // tiles that see geometry and the number of tiles in the order.
     const size_t pre_stride = (size_t)t.mine + 64;          // per frame: tile costs / order, then the sched words
@@ -550,7 +575,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         // Batch: every frame's pre-pass (exact culling + coverage order; no probe: the frames' chains overlap whatever their order), its
         // results left pre_stride apart; then one small kernel turns the counts into the table the render kernel looks work items up in.
         // Slices stay at the host's 8 (resident_lanes = 0: the pool is never short of heavy pixels).
-        const bool cull = (desc->tune[3] & 3) == 0;
+        const bool cull = (flags & 3u) == 0u;
         HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));                          // culled pixels are never written
         if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
         if (ctx->batch_table.n < 2 * (size_t)frames) { int rc = ctx->batch_table.alloc(2 * (size_t)frames); if (rc) return rc; }
@@ -560,7 +585,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             BatchFrame& e = ctx->batch_host[(size_t)i];
             const float cam12[12] = {bc.origin.x, bc.origin.y, bc.origin.z, bc.lower_left_corner.x, bc.lower_left_corner.y, bc.lower_left_corner.z,
                                      bc.horizontal.x, bc.horizontal.y, bc.horizontal.z, bc.vertical.x, bc.vertical.y, bc.vertical.z};
-            std::memcpy(e.cam_origin, cam12, sizeof cam12);                                   // origin, llc, horizontal, vertical are contiguous
+            static_assert(sizeof cam12 == sizeof e.cam, "camera block");
+            std::memcpy(e.cam, cam12, sizeof cam12);
             e.sun_dir[0] = batch->sun_dirs[i].x; e.sun_dir[1] = batch->sun_dirs[i].y; e.sun_dir[2] = batch->sun_dirs[i].z;
             e.order_base = (uint32_t)(pre_stride * (size_t)i);
             e.image_slot = (uint32_t)i;
@@ -571,11 +597,11 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
                                   ctx->batch_table.p, (uint32_t)frames, (uint32_t)pre_stride));
         // rng_mode 0 at enough samples for a pixel to be a long chain: every frame's heavy tiles re-sorted by measured cost, as for a single
         // frame (the probe launch below in this function) -- one probe per frame, 6 ms each at 1080p, against a frame of a second
-        if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 256) {
+        if (!(flags & DSRT_TUNE_NO_PROBE) && desc->rng_mode == 0 && f.spp >= 256) {
             if (ctx->probe_queue.n < 1024) { int rc = ctx->probe_queue.alloc(1024); if (rc) return rc; }
             for (int i = 0; i < frames; ++i) {
                 RenderArgs pa = a;
-                std::memcpy(pa.frame.cam_origin, ctx->batch_host[(size_t)i].cam_origin, 12 * sizeof(float));
+                std::memcpy(pa.frame.cam, ctx->batch_host[(size_t)i].cam, sizeof pa.frame.cam);
                 std::memcpy(pa.frame.sun_dir, ctx->batch_host[(size_t)i].sun_dir, 3 * sizeof(float));
                 pa.frame.spp = 4; pa.frame.chunks = 1; pa.frame.chunk_len = 4;
                 pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
@@ -596,8 +622,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         a.batch = ctx->batch_table.p; a.batch_order = ctx->tile_order.p; a.batch_frames = 2u * (uint32_t)frames;
         a.batch_frame_pixels = (uint32_t)(out_pixels / (size_t)frames);        // whole images, or the padded compact shard buffers, one after another
     } else
-    if ((desc->tune[3] & 3) != 1 && t.mine > 0) {
-        const bool cull = (desc->tune[3] & 3) != 2 && desc->collect_counters == 0;
+    if ((flags & 3u) != DSRT_TUNE_NATURAL_ORDER && t.mine > 0) {
+        const bool cull = (flags & 3u) != DSRT_TUNE_NO_CULLING && desc->collect_counters == 0;
         if (cull) {                                             // culled pixels are never written: they are the zeros put here
             HIP_TRY(hipMemsetAsync(d_rgb8, 0, out_pixels * 3, stream));
             if (d_f32) HIP_TRY(hipMemsetAsync(d_f32, 0, out_pixels * 3 * sizeof(float), stream));
@@ -607,15 +633,15 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         a.frame.tile_order = ctx->tile_order.p;
         // Probe: the render kernel itself at kProbeSpp samples per pixel (reference stream, nothing stored)
         // measures what every tile costs; the heavy tiles are then re-sorted by that.  Worth its 0.5 % only when a pixel is a
-        // long chain; tune[3] bit 3 (value 8) switches it off.
+        // long chain; DSRT_TUNE_NO_PROBE switches it off.
         constexpr int kProbeSpp = 4;          // x every pixel of the heavy tiles: 7 ms at 1080p, near frame.  (1, 2, 4 or 8 samples order the tiles equally well.)
         // Its work items are tiny, so the probe has 64 queue words of its own (path_machine.h, ST_FETCH): on the frame's single queue word
         // the same launch took 27 ms.
         // Only with the reference's stream: in rng_mode 1 a pixel is cut into slices and lanes share samples, so there is no long chain to start
         // early, and the coverage order alone is better (interleaved medians, near frame: 1046 -> 1037 ms, one of 8 shares 176 -> 167 ms).
-        if (!(desc->tune[3] & 8) && desc->rng_mode == 0 && f.spp >= 64 * kProbeSpp) {
+        if (!(flags & DSRT_TUNE_NO_PROBE) && desc->rng_mode == 0 && f.spp >= 64 * kProbeSpp) {
             RenderArgs pa = a;
-            const int probe_spp = (desc->tune[3] & 64) ? 2 * kProbeSpp : kProbeSpp;                  // experiments
+            const int probe_spp = (xp & 64u) ? 2 * kProbeSpp : kProbeSpp;                  // experiment
             pa.frame.spp = probe_spp; pa.frame.chunks = 1; pa.frame.chunk_len = probe_spp;
             pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
             pa.tile_work = ctx->tile_work.p;
@@ -809,23 +835,25 @@ struct SceneFingerprint {
     bool operator==(const SceneFingerprint& o) const { return valid && o.valid && h[0] == o.h[0] && h[1] == o.h[1] && !std::memcmp(counts, o.counts, sizeof counts); }
 };
 SceneFingerprint g_dropin_fp;
-DevBuf<uint64_t> g_dropin_hash;
+// two words of device memory for the hash; like g_dropin_ctx a raw pointer that is never freed: a destructor at static-destruction time
+// would call hipFree after the HIP runtime may already be gone
+uint64_t* g_dropin_hash = nullptr;
 
 int fingerprint_device_scene(const GPUScene& d, SceneFingerprint& fp) {
     fp = SceneFingerprint{};
     const int counts[7] = {d.num_triangles, d.num_spheres, d.num_materials, d.num_bvh_nodes, d.num_textures, d.texture_pool_floats, d.tri_indices ? 1 : 0};
     std::memcpy(fp.counts, counts, sizeof counts);
     for (int c : counts) if (c < 0) { set_error("scene has a negative count"); return DSRT_ERR_INVALID; }
-    if (g_dropin_hash.n < 2) { int rc = g_dropin_hash.alloc(2); if (rc) return rc; }
-    HIP_TRY(hipMemsetAsync(g_dropin_hash.p, 0, 2 * sizeof(uint64_t), nullptr));
+    if (!g_dropin_hash) HIP_TRY(hipMalloc((void**)&g_dropin_hash, 2 * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(g_dropin_hash, 0, 2 * sizeof(uint64_t), nullptr));
     struct Arr { const void* p; size_t bytes; } arrs[7] = {
         {d.triangles, (size_t)d.num_triangles * sizeof(GPUTriangle)}, {d.spheres, (size_t)d.num_spheres * sizeof(GPUSphere)},
         {d.materials, (size_t)d.num_materials * sizeof(GPUMaterial)}, {d.bvh_nodes, (size_t)d.num_bvh_nodes * sizeof(GPUBVHNode)},
         {d.textures, (size_t)d.num_textures * sizeof(GPUTextureHeader)}, {d.texture_pool, (size_t)d.texture_pool_floats * sizeof(float)},
         {d.tri_indices, d.tri_indices ? (size_t)d.num_triangles * sizeof(int) : 0}};
     for (int a = 0; a < 7; ++a)
-        if (arrs[a].p && arrs[a].bytes) HIP_TRY(launch_content_hash((const uint32_t*)arrs[a].p, arrs[a].bytes / 4, 0x9E3779B97F4A7C15ull * (uint64_t)(a + 1), g_dropin_hash.p, nullptr));
-    HIP_TRY(hipMemcpy(fp.h, g_dropin_hash.p, sizeof fp.h, hipMemcpyDeviceToHost));
+        if (arrs[a].p && arrs[a].bytes) HIP_TRY(launch_content_hash((const uint32_t*)arrs[a].p, arrs[a].bytes / 4, 0x9E3779B97F4A7C15ull * (uint64_t)(a + 1), g_dropin_hash, nullptr));
+    HIP_TRY(hipMemcpy(fp.h, g_dropin_hash, sizeof fp.h, hipMemcpyDeviceToHost));
     fp.valid = true;
     return DSRT_OK;
 }

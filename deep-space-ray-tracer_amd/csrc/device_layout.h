@@ -64,8 +64,10 @@ struct DeviceScene {
     int   stack_need;          // deepest the traversal stack can get for this BVH
 };
 
+constexpr int kCamOrigin = 0, kCamLlc = 3, kCamHorizontal = 6, kCamVertical = 9;     // offsets into FrameParams::cam / BatchFrame::cam
+
 struct FrameParams {
-    float cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3];
+    float cam[12];             // origin, lower-left corner, horizontal, vertical (kCamOrigin ... below), as GPUCamera has them
     float sun_dir[3], sun_radiance[3];
     int   sun_enabled;
     int   width, height, spp, max_depth;
@@ -89,7 +91,7 @@ struct FrameParams {
 // sun and image slot are filled by the host (the same in both entries of a frame), the counts by dsrt_batch_table_kernel from what each
 // frame's pre-pass left in its `sched` words.
 struct BatchFrame {
-    float    cam_origin[3], cam_llc[3], cam_horizontal[3], cam_vertical[3];     // contiguous: path_machine.h reads them as 12 floats
+    float    cam[12];          // as FrameParams::cam
     float    sun_dir[3];
     uint32_t item_end;         // work items of frames 0 .. this one (exclusive end of this frame's range in the batch queue)
     uint32_t order_base;       // where this frame's tile order starts in RenderArgs::batch_order
@@ -112,8 +114,7 @@ struct RenderArgs {
                                //   [1] n_live   tiles in tile_order: the shard's tiles minus those proven empty
                                //   [2] spread   lanes per wave (1..64) that serve the heavy queue first; the others start on the light one
     uint32_t* probe_queue;     // probe launch only: 64 queue words, 64 bytes apart (path_machine.h, ST_FETCH)
-    int       hot_shift;       // rng_mode 0: 0 = off; s > 0: pixels of the first n_heavy >> (s - 1) tiles of the order raise their wave's issue priority
-    int       hot_graded;      //   1 = three levels (that share, a quarter and a sixteenth of it), 0 = one level
+    int       hot;             // rng_mode 0: 1 = a wave that holds a pixel of a heavy tile raises its issue priority (render_body)
     const BatchFrame* batch;   // batch launch only: the table, batch_frames entries (two per frame)
     const uint32_t* batch_order; //   the frames' tile orders, BatchFrame::order_base apart
     uint32_t  batch_frames, batch_frame_pixels;   // table entries in the launch; output pixels per frame (W*H, or a shard's padded tile buffer)

@@ -106,6 +106,63 @@ gather_kernel(const float4* __restrict__ table, uint32_t n_rec, int iters, int l
     if (acc == 123.456f) sink[glane] = acc;           // keeps the loads alive; never true for the table's contents
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The vector-ALU ISSUE ceiling (dsrt_microbench_valu).  The render kernel is bound by VALU issue, so the ceiling it is priced against
+// has to be measured, not assumed: `waves_per_simd` waves on every SIMD of the chip each run `iters` x 32 instructions of ONE kind
+// from EIGHT INDEPENDENT accumulator streams (no instruction reads the result of any of the seven before it), written as inline
+// assembly so that the instruction counted is the instruction issued.  Every wave times itself with the shader-clock counter
+// (s_memtime); cycles per wave-instruction per SIMD = mean wave time / (waves_per_simd * instructions per wave).
+//   kind 0  v_fma_f32        kind 1  v_pk_fma_f32 (two fp32 results per lane)      kind 2  v_pk_mul_f32
+//   kind 3  v_cndmask_b32 (reads vcc)                                              kind 4  v_max3_f32
+// `lane_mask`: the lanes of every wave that execute the loop (the rest branch around it): does a half-empty wave issue faster?
+// ---------------------------------------------------------------------------------------------------------------
+typedef float v2f_mb __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+valu_kernel(int iters, unsigned long long lane_mask, unsigned long long* __restrict__ wave_cycles, float* __restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const float seed = (float)(threadIdx.x & 7u) * 1e-3f;
+    float a0 = seed, a1 = seed + 1.0f, a2 = seed + 2.0f, a3 = seed + 3.0f, a4 = seed + 4.0f, a5 = seed + 5.0f, a6 = seed + 6.0f, a7 = seed + 7.0f;
+    v2f_mb p0 = {a0, a1}, p1 = {a1, a2}, p2 = {a2, a3}, p3 = {a3, a4}, p4 = {a4, a5}, p5 = {a5, a6}, p6 = {a6, a7}, p7 = {a7, a0};
+    const float m = 0.99999994f, c = 1e-7f;
+    const v2f_mb pm = {m, m}, pc = {c, c};
+    unsigned long long t0 = 0, t1 = 0;
+    if ((lane_mask >> lane) & 1ull) {
+        t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < iters; ++it) {
+#define DSRT_R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+            if (KIND == 0) {
+#define DSRT_FMA(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
+                asm volatile(DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA)
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            } else if (KIND == 1) {
+#define DSRT_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
+                asm volatile(DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA)
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc));
+            } else if (KIND == 2) {
+#define DSRT_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n\t"
+                asm volatile(DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL)
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm));
+            } else if (KIND == 3) {
+#define DSRT_CND(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
+                asm volatile("v_cmp_gt_f32 vcc, %8, %9\n\t" DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND)
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c) : "vcc");
+            } else {
+#define DSRT_MAX3(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n\t"
+                asm volatile(DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3)
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+            }
+        }
+        t1 = __builtin_readcyclecounter();
+    }
+    const unsigned long long first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(lane_mask));
+    if (lane == (uint32_t)first) wave_cycles[gwave] = t1 - t0;
+    const float r = (((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7))) + (((p0.x + p1.y) + (p2.x + p3.y)) + ((p4.x + p5.y) + (p6.x + p7.y)));
+    if (r == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <int MODE>
 hipError_t launch_gather(bool dep, const float4* table, uint32_t n_rec, int iters, int live, int pad, float* sink, int blocks, hipStream_t s) {
     if (dep) hipLaunchKernelGGL((gather_kernel<MODE, true>), dim3(blocks), dim3(256), 0, s, table, n_rec, iters, live, pad, sink);
@@ -174,6 +231,59 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
         if (live_lanes >= 64 || (x & 63u) < (uint32_t)live_lanes) live_total += 1.0;
     }
     *out_records = live_total * (double)iters;
+    cleanup();
+    return DSRT_OK;
+}
+
+extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
+                                    double* out_cycles_per_instruction_per_simd) {
+    if (kind < 0 || kind > 4 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms || !out_wave_instructions ||
+        !out_cycles_per_instruction_per_simd) {
+        dsrt::set_error("dsrt_microbench_valu: bad argument");
+        return DSRT_ERR_INVALID;
+    }
+    unsigned long long* cycles = nullptr;
+    float* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (cycles) (void)hipFree(cycles);
+        if (sink) (void)hipFree(sink);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    MB_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MB_TRY(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount * waves_per_simd;          // 256 threads = one wave per SIMD of a CU per block
+    const size_t waves = (size_t)blocks * 4;
+    MB_TRY(hipMalloc((void**)&cycles, waves * sizeof(unsigned long long)));
+    MB_TRY(hipMalloc((void**)&sink, waves * 64 * sizeof(float)));
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    auto run = [&](int n) -> hipError_t {
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(valu_kernel<0>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
+            case 1: hipLaunchKernelGGL(valu_kernel<1>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
+            case 2: hipLaunchKernelGGL(valu_kernel<2>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
+            case 3: hipLaunchKernelGGL(valu_kernel<3>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
+            default: hipLaunchKernelGGL(valu_kernel<4>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
+        }
+        return hipGetLastError();
+    };
+    MB_TRY(run(iters < 256 ? iters : 256));
+    MB_TRY(hipDeviceSynchronize());
+    MB_TRY(hipEventRecord(e0, nullptr));
+    MB_TRY(run(iters));
+    MB_TRY(hipEventRecord(e1, nullptr));
+    MB_TRY(hipEventSynchronize(e1));
+    MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
+    std::vector<unsigned long long> host(waves);
+    MB_TRY(hipMemcpy(host.data(), cycles, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (unsigned long long c : host) sum += (double)c;
+    const double per_wave = (double)iters * (kind == 3 ? 33.0 : 32.0);
+    *out_wave_instructions = per_wave * (double)waves;
+    *out_cycles_per_instruction_per_simd = (sum / (double)waves) / ((double)waves_per_simd * per_wave);
     cleanup();
     return DSRT_OK;
 }

@@ -308,9 +308,10 @@ int dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc_in, cons
         // EVERY rank renders its interleaved tiles of EVERY frame, as batch launches (dsrt_render_batch with a shard: the rank's tiles of all
         // the frames of a launch are one pool of work).  Loads are equal by construction (each rank has every 8th tile of every frame), every
         // frame's serial chains are spread over all GPUs AND run under the other frames' bulk, and the collective is one gather per launch for
-        // all its frames.  One rank's share of the 99-pose approach at 1080p x 250 on one MI355X: 8 ranks 0.29 s in rng_mode 0 (5.8x the
-        // single-GPU rate; whole frames dealt by cost: 5.0x, round-robin: 4.2x), 0.24 s in rng_mode 1 (7.3x).  Frames go nearest (costliest)
-        // first; as many per launch as its 32-bit work-item numbers allow, 128 at most.
+        // all its frames.  PROJECTION, not a measurement of an N-GPU run: one rank's share of the 99-pose approach at 1080p x 250, timed alone
+        // on one MI355X (no gather, no xGMI traffic, no root de-interleave), takes 0.29 s of 8 in rng_mode 0 -- which would be 5.8x the
+        // single-GPU rate (whole frames dealt by cost: 5.0x, round-robin: 4.2x) -- and 0.24 s in rng_mode 1 (7.3x).  Frames go nearest
+        // (costliest) first; as many per launch as its 32-bit work-item numbers allow, 128 at most.
         constexpr size_t kGroup = 128;
         int rc;
         size_t padded_bytes = image_bytes;

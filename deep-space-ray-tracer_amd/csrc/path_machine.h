@@ -30,14 +30,13 @@ enum : int {
 // touches L (the next hit's terms, the end of the sample), i.e. in the reference's order; at most one delegated ray per path
 // is outstanding.  This shortens the one thing rng_mode 0 cannot parallelise -- a pixel's serial chain of samples -- whenever
 // the chip is not full: far frames, the tail of a frame, one rank's share of a multi-GPU job.
-//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding; bits 9-10: priority level;
+//   Lane::aux  bits 0-5 lane number; bit 8 kAwait: a delegated shadow ray of this path is outstanding; bit 9 kHot: pixel of a heavy tile;
 //              bits 16-22: (owner lane + 1) while this lane traces a shadow ray for `owner`;
 //              bits 24-31: probe launch only: rays traced for the current pixel (saturating)
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
-constexpr int kHotBit = 9;                   // bits 9-10: rng_mode 0: issue-priority level of the pixel this lane is working on
-constexpr uint32_t kHotMask = 3u << kHotBit;
+constexpr uint32_t kHot = 1u << 9;           // rng_mode 0: the pixel this lane is working on belongs to a heavy tile (its wave asks for issue priority)
 
 // Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
 // the DS unit retires a wave's operations in order, so no hardware instruction is needed; what IS needed is that the compiler
@@ -498,15 +497,9 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         ln.chunk = 0;
         const bool none = item >= (heavy ? heavy_items : light_items);
         if constexpr (!PROBE && RNGMODE == 0) {
-            // Issue priority for the long chains (render_body raises the wave's s_setprio while it holds one): how far up the
-            // costliest-first order this pixel's tile stands, as a level 0-3.
-            ln.aux &= ~kHotMask;
-            if (args.hot_shift > 0 && heavy && !none) {
-                const uint32_t r = item / tt, base = n_heavy >> (args.hot_shift - 1);
-                uint32_t level = r < base ? 1u : 0u;
-                if (args.hot_graded) level += (r < (base >> 2) ? 1u : 0u) + (r < (base >> 4) ? 1u : 0u); else level *= 3u;
-                ln.aux |= level << kHotBit;
-            }
+            // Issue priority for the long chains: render_body raises the wave's s_setprio while it holds a pixel of a heavy tile.
+            ln.aux &= ~kHot;
+            if (args.hot && heavy && !none) ln.aux |= kHot;
         }
         if (sliced) { ln.chunk = item % pp; item /= pp; }
         if (!heavy) item += n_heavy * tt;                     // position in tile_order x pixels per tile
@@ -599,8 +592,8 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             float jy = ((float)sample + rand01(rng)) / (float)spp;
             float u = ((float)px + jx) / (float)(W - 1);                     // :952-953
             float v = ((float)ky + jy) / (float)(H - 1);
-            const float* cam = BATCH ? args.batch[ln.frame].cam_origin : P.cam_origin;       // origin, lower-left corner, horizontal, vertical: 12 floats in a row
-            const F3 cam_o = ld3(cam), cam_llc = ld3(cam + 3), cam_h = ld3(cam + 6), cam_v = ld3(cam + 9);
+            const float* cam = BATCH ? args.batch[ln.frame].cam : P.cam;
+            const F3 cam_o = ld3(cam + kCamOrigin), cam_llc = ld3(cam + kCamLlc), cam_h = ld3(cam + kCamHorizontal), cam_v = ld3(cam + kCamVertical);
             ro = cam_o;
             rd = ((cam_llc + (cam_h * u)) + (cam_v * v)) - cam_o;           // :957-961
             depth = 0;

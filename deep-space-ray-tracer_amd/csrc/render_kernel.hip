@@ -88,11 +88,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
         if constexpr (!PROBE && RNGMODE == 0) {
             // Waves that hold a pixel of a heavy tile ask the SIMD's arbiter for priority over waves that only hold background pixels
             // (levels: device_api.hip).  Scheduling only.
-            if (args.hot_shift > 0) {
-                const uint32_t lv = (ln.aux & kHotMask) >> kHotBit;
-                if (wave_any(lv == 3u)) __builtin_amdgcn_s_setprio(3);
-                else if (wave_any(lv == 2u)) __builtin_amdgcn_s_setprio(2);
-                else if (wave_any(lv == 1u)) __builtin_amdgcn_s_setprio(1);
+            if (args.hot) {
+                if (wave_any((ln.aux & kHot) != 0u)) __builtin_amdgcn_s_setprio(3);
                 else __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -316,14 +313,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_prob
 // cost word: bit 31 = the tile has at least one block that is not provably empty; low bits = pixels that see geometry.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ bool block_footprint_misses_root(const DeviceScene& S, const FrameParams& P, int x0, int ky0) {
-    const double o[3] = {P.cam_origin[0], P.cam_origin[1], P.cam_origin[2]};
+    const double o[3] = {P.cam[kCamOrigin + 0], P.cam[kCamOrigin + 1], P.cam[kCamOrigin + 2]};
     const double ulo = (double)(x0 - 1) / (double)(P.width - 1), uhi = (double)(x0 + 9) / (double)(P.width - 1);
     const double vlo = (double)(ky0 - 1) / (double)(P.height - 1), vhi = (double)(ky0 + 9) / (double)(P.height - 1);
     const double us[4] = {ulo, uhi, uhi, ulo}, vs[4] = {vlo, vlo, vhi, vhi};
     double dir[4][3], mid[3] = {0, 0, 0};
     for (int c = 0; c < 4; ++c)
         for (int a = 0; a < 3; ++a) {
-            dir[c][a] = ((double)P.cam_llc[a] + us[c] * (double)P.cam_horizontal[a] + vs[c] * (double)P.cam_vertical[a]) - o[a];
+            dir[c][a] = ((double)P.cam[kCamLlc + a] + us[c] * (double)P.cam[kCamHorizontal + a] + vs[c] * (double)P.cam[kCamVertical + a]) - o[a];
             mid[a] += dir[c][a];
         }
     double rel[8][3];
@@ -351,8 +348,7 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
                                                              const BatchFrame* __restrict__ batch, uint32_t stride) {
     FrameParams P = P0;
     if (batch) {
-        const float* cam = batch[blockIdx.y].cam_origin;
-        for (int a = 0; a < 3; ++a) { P.cam_origin[a] = cam[a]; P.cam_llc[a] = cam[3 + a]; P.cam_horizontal[a] = cam[6 + a]; P.cam_vertical[a] = cam[9 + a]; }
+        for (int a = 0; a < 12; ++a) P.cam[a] = batch[blockIdx.y].cam[a];
         cost += (size_t)blockIdx.y * stride;
     }
     const uint32_t blocks_per_tile = (uint32_t)((P.tile >> 3) * (P.tile >> 3));
@@ -375,8 +371,8 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
     if (x < P.width && row < P.height) {
         const int ky = P.height - 1 - row;
         const float u = ((float)x + 0.5f) / (float)(P.width - 1), v = ((float)ky + 0.5f) / (float)(P.height - 1);
-        const F3 ro = ld3(P.cam_origin);
-        const F3 rd = ((ld3(P.cam_llc) + (ld3(P.cam_horizontal) * u)) + (ld3(P.cam_vertical) * v)) - ro;
+        const F3 ro = ld3(P.cam + kCamOrigin);
+        const F3 rd = ((ld3(P.cam + kCamLlc) + (ld3(P.cam + kCamHorizontal) * u)) + (ld3(P.cam + kCamVertical) * v)) - ro;
         const F3 rinv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
         for (int i = 0; i < S.num_spheres && !hit; ++i) { float t; F3 n; hit = hit_sphere(S.spheres[i], ro, rd, kTMax, t, n); }
         float t_entry;

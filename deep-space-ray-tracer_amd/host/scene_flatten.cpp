@@ -142,7 +142,7 @@ using namespace dsrt;
 extern "C" {
 
 const char* dsrt_last_error(void) { return dsrt::g_last_error.c_str(); }
-int dsrt_abi_version(void) { return 3; }     // 3: round 2 (DsrtStats grew, rng_mode 1 sums, dsrt_render_batch, dsrt_multi_*)
+int dsrt_abi_version(void) { return DSRT_ABI_VERSION; }     // include/dsrt.h: the one place the number is written
 
 DsrtHostScene* dsrt_host_scene_create(void) { return new DsrtHostScene(); }
 void dsrt_host_scene_destroy(DsrtHostScene* hs) { delete hs; }

@@ -12,10 +12,12 @@ one frame goes straight on to the next frame -- so no chip time is lost to any f
 overlap: the 99-pose sequence runs at 56 frames/s in rng_mode 0 on one MI355X against 40 with 16 separate launches in flight.
 
 With more than one rank (one process per GPU, torch.distributed) the job splits one of two ways:
-  split="frames"  poses are dealt round-robin: rank r renders frames r, r + N, ... whole; no collective on the data path.  The
-                  natural shard of a sequence, and the only one that scales in rng_mode 0 (a pixel is a serial chain however many
-                  GPUs share its frame).
-  split="tiles"   every frame is sharded by interleaved screen tiles over all ranks and gathered to rank 0 (one gather per frame).
+  split="tiles"   (default) every rank renders ITS interleaved screen tiles of EVERY frame, as sharded batch launches: the rank's tiles of all
+                  the frames of a launch are one pool of work, so loads are equal by construction and a frame's serial chains run under the
+                  other frames' bulk; one gather per launch for all its frames, de-interleave on rank 0.
+  split="frames"  the no-collective alternative: whole poses are dealt to ranks (by estimated cost, or round-robin); bound by the nearest
+                  frame itself at 8 ranks.
+Neither split has run on more than one GPU yet; the speed-ups quoted in DESIGN.md section 5 are projections from single-GPU shard probes.
 """
 import numpy as np
 
@@ -177,8 +179,9 @@ def render_batches(d, ctx, hs_frame, frame_ids, W, H, spp, depth, per_launch=32,
                 ctxs[slot].render_batch(desc, list(cams), [tuple(s) for s in suns], bufs[slot].data_ptr(), stream=streams[slot].cuda_stream)
                 host[slot][:len(group) * n_img].copy_(bufs[slot][:len(group) * n_img], non_blocking=True)
             held[slot] = group
-        retire(0)
-        retire(1)
+        n_launches = (len(ids) + per_launch - 1) // per_launch
+        retire(n_launches % 2)                    # oldest first: the last launch sits in slot (n_launches - 1) % 2, the one before it in the other
+        retire((n_launches + 1) % 2)
     finally:
         for st in streams:
             st.synchronize()

@@ -32,7 +32,11 @@ extern "C" {
 #define DSRT_ERR_COMM        -9   /* an RCCL call failed                                         */
 
 const char* dsrt_last_error(void);
-/* ABI version of this header (bumped on any signature or struct change; 3 = round 2: DsrtStats grew, dsrt_render_batch, dsrt_multi_*). */
+/* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
+ * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
+ * refused; dsrt_selftest_devkat, dsrt_microbench_valu).  dsrt_abi_version() returns the value the library was compiled with;
+ * bindings parse this line (capi.header_abi_version) and compare. */
+#define DSRT_ABI_VERSION 4
 int dsrt_abi_version(void);
 
 /* ===================================================================================== */
@@ -136,6 +140,9 @@ int dsrt_write_png(const char* path, const uint8_t* rgb, int width, int height);
 /* ===================================================================================== */
 typedef struct DsrtContext DsrtContext;
 
+/* The first call of either of these two sets the environment variable GPU_MAX_HW_QUEUES to 16 if the host has not set it (frames in flight
+ * on separate streams only overlap on the device if each stream has a hardware queue of its own, and the HIP runtime reads the variable
+ * when it initialises): a host that minds sets the variable itself, or initialises HIP, before calling.  Loading the library changes nothing. */
 int  dsrt_device_count(void);
 int  dsrt_ctx_create(int device, DsrtContext** out);
 void dsrt_ctx_destroy(DsrtContext* ctx);
@@ -176,17 +183,19 @@ typedef struct DsrtRenderDesc {
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, flags}.  None of them
-                                       changes a pixel.  Flags: low two bits 1 = natural tile order and no empty-tile culling, 2 = costliest-
-                                       first order but no culling; +4 = idle lanes do not trace shadow rays for busy ones; +8 = no probe
-                                       launch to refine the order; +16 = rng_mode 1: idle lanes do not take over samples of busy lanes;
-                                       +64 = 8 probe samples instead of 4; bits 8-19 = rng_mode 1: slices per heavy pixel (0 = chosen by
-                                       the pre-pass); bits 23-25 = rng_mode 0 issue priority: 0 = waves holding a heavy tile's pixel run
-                                       above the rest, 7 = off, 2-6 and bit 26 = finer grades (experiments); bit 27 = counting build of
-                                       rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as bit patterns, 100 MHz
-                                       ticks, instead of the colour (tools/chain_timeline.py); bits 28-29 = rng_mode 1: least samples per
-                                       work item of a background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512; bit 31 = background pixels one
-                                       item each (see device_layout.h, path_machine.h, dsrt_tile_cost_kernel) */
+                                       changes a pixel (tested against the oracle in every combination).  Flags, DSRT_TUNE_* below: the low
+                                       two bits choose the pre-pass, the others switch one scheduling measure off each.  Any other bit is
+                                       refused (DSRT_ERR_INVALID): development switches are not part of this ABI -- they are read from the
+                                       environment variable DSRT_EXPERIMENT (csrc/device_api.hip) */
 } DsrtRenderDesc;
+
+#define DSRT_TUNE_NATURAL_ORDER   1    /* tiles in natural order, no empty-tile culling (no pre-pass at all)                   */
+#define DSRT_TUNE_NO_CULLING      2    /* costliest-first order, but no tile is dropped as provably empty                     */
+#define DSRT_TUNE_NO_HELPERS      4    /* idle lanes do not trace shadow rays for busy lanes of their wave                    */
+#define DSRT_TUNE_NO_PROBE        8    /* no probe launch to refine the tile order (rng_mode 0)                               */
+#define DSRT_TUNE_NO_STEALING    16    /* rng_mode 1: idle lanes do not take over samples of busy lanes                       */
+#define DSRT_TUNE_NO_PRIORITY    32    /* rng_mode 0: waves holding a heavy tile's pixel do not raise their issue priority    */
+#define DSRT_TUNE_FLAG_MASK      63
 
 typedef struct DsrtStats {
     float    kernel_ms;             /* HIP events around the render kernel on the given stream (0 if timing off) */
@@ -297,9 +306,10 @@ int  dsrt_multi_scene_upload(DsrtMulti* m, const GPUScene* host_scene);
  * are ignored.  Optional outputs: per-rank render time in ms (HIP events; N floats) and the wall time of the whole call. */
 int  dsrt_multi_render_frame(DsrtMulti* m, const DsrtRenderDesc* desc, const GPUCamera* cam, const float sun_dir_model[3],
                              uint8_t* h_rgb8, float* kernel_ms_per_rank, double* seconds);
-/* MANY frames of the resident scene (src/main.cpp's frame loop): frame i is rendered WHOLE by rank i mod N -- no collective --
- * with `frames_in_flight` frames going per rank on separate streams.  cams[i] / sun_dirs[3 i ..] as from dsrt_camera_look_at /
- * dsrt_pose_to_frame.  h_images may be NULL (timing only) or hold n_frames host pointers (NULL entries are skipped). */
+/* MANY frames of the resident scene (src/main.cpp's frame loop): every rank renders ITS interleaved tiles of EVERY frame as sharded batch
+ * launches (dsrt_render_batch with a shard), nearest frames first, one gather per launch for all its frames and the de-interleave on rank 0.
+ * cams[i] / sun_dirs[3 i ..] as from dsrt_camera_look_at / dsrt_pose_to_frame.  h_images may be NULL (timing only) or hold n_frames host
+ * pointers (NULL entries are skipped). */
 int  dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc, const GPUCamera* cams, const float* sun_dirs, int n_frames,
                                 uint8_t* const* h_images, double* seconds);
 
@@ -313,6 +323,13 @@ int  dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc, const 
  * Returns the kernel time (HIP events) and the number of records gathered.  No reference interface: measurement only. */
 int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, int pad_valu, size_t table_bytes, int iters,
                            float* out_ms, double* out_records);
+
+/* The other calibration: the vector-ALU issue ceiling.  `waves_per_simd` (1..8) waves on every SIMD of the chip each issue iters x 32
+ * instructions of one kind from eight independent streams (kind 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul_f32, 3 v_cndmask_b32, 4 v_max3_f32);
+ * only the lanes in `lane_mask` execute them.  Returns the kernel time, the wave-instructions issued, and the shader cycles per
+ * wave-instruction per SIMD from the waves' own cycle counters.  No reference interface: measurement only. */
+int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
+                         double* out_cycles_per_instruction_per_simd);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

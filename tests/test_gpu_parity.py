@@ -369,14 +369,33 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
     scene = hs.view(cam, SUN)
     want_rgb, want_f32, _ = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 64, 68, 3 << 23, 7 << 23, (1 << 26) + (1 << 23)):        # include/dsrt.h, DsrtRenderDesc.tune
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 36, 63 - 1):        # include/dsrt.h, DSRT_TUNE_*
         rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
+    # bits the ABI does not define are refused, not ignored
+    for flags in (64, 1 << 23, -(1 << 31)):
+        with pytest.raises(dsrt.DsrtError):
+            gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)))
+    # the development switches (env DSRT_EXPERIMENT, read per call) are scheduling only as well
+    try:
+        for xp in (64, 1 << 20):
+            os.environ["DSRT_EXPERIMENT"] = str(xp)
+            rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth), want_f32=True)
+            assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), xp
+    finally:
+        os.environ.pop("DSRT_EXPERIMENT", None)
     # rng_mode 1 sums samples as integers, so neither the scheduling switches nor sample stealing (+16 switches it off) may move a bit
     a, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
-    for flags in (12, 16, 28, 1 + 16, 2, -(1 << 31)):
+    for flags in (12, 16, 28, 1 + 16, 2):
         b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, flags)))
         assert np.array_equal(a, b), flags
+    try:
+        for xp in (1 << 31, 16 << 8, 1 << 28):                      # background pixels one item each; 16 slices per heavy pixel; 64-sample light items
+            os.environ["DSRT_EXPERIMENT"] = str(xp)
+            b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
+            assert np.array_equal(a, b), xp
+    finally:
+        os.environ.pop("DSRT_EXPERIMENT", None)
 
 
 def test_cli_renders_pose_frames_like_the_library(dsrt, oracle, tmp_path):
@@ -549,8 +568,8 @@ def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
         if frame == 70:
             assert st.tiles_culled > 0.8 * st.tiles_total
         else:
-            # the priority switches only exist on a chip full of heavy work, i.e. at this size: scheduling only, so the same bits
-            for flags in (7 << 23, (1 << 26) + (3 << 23)):
+            # the priority switch only exists on a chip full of heavy work, i.e. at this size: scheduling only, so the same bits
+            for flags in (32,):
                 again, again32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, tune=(0, 0, 0, flags)), want_f32=True)
                 assert np.array_equal(again, want) and np.array_equal(again32.view(np.uint32), want32.view(np.uint32)), flags
 

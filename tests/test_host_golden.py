@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(dsrt):
     import re
     declared = set(re.findall(r"\b(dsrt_[a-z0-9_]+|gpu_render_scene)\s*\(", header))
     assert declared == set(dsrt.capi.EXPORTS)
-    assert dsrt.lib.dsrt_abi_version() == 3
+    assert dsrt.lib.dsrt_abi_version() == dsrt.capi.header_abi_version() >= 4
 
 
 def test_pose_file_and_world_to_model_transform(dsrt):

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of render settings in ONE process on ONE box (development aid): each configuration `rng:tune3[:spp]` is rendered
+"""Interleaved A/B of render settings in ONE process on ONE box (development aid): each configuration `rng:switches[:loop knobs]` (the low six bits
+of `switches` are DsrtRenderDesc.tune[3], the DSRT_TUNE_* flags of include/dsrt.h; the rest goes into the environment variable DSRT_EXPERIMENT, the
+library's development switches, csrc/device_api.hip) is rendered
 --reps times, round-robin, and the medians of the kernel times (HIP events) are printed.  Devices differ by a few per cent, so
 settings are only ever compared inside one run of this tool."""
 import argparse
@@ -45,16 +47,18 @@ def main():
         parts = [int(x) for x in c.split(":")]
         rng, t3 = parts[0], parts[1]
         t0, t1, t2 = (parts[2:5] + [0, 0, 0])[:3]                     # optional: min_walk_iters : advance_budget : leaf_ratio4
-        descs.append(d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, t3)))
-    lay = d.shard_layout(descs[0])
+        descs.append((d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, t3 & 63)), (t3 & 0xFFFFFFFF) & ~63))
+    lay = d.shard_layout(descs[0][0])
     buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
     import time
     times = [[] for _ in descs]
     walls = [[] for _ in descs]
-    for dsc in descs:
+    for dsc, xp in descs:
+        os.environ["DSRT_EXPERIMENT"] = str(xp)                                   # read by the library at every render call
         ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True)           # warm-up
     for _ in range(a.reps):
-        for i, dsc in enumerate(descs):
+        for i, (dsc, xp) in enumerate(descs):
+            os.environ["DSRT_EXPERIMENT"] = str(xp)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             times[i].append(ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True).kernel_ms)
