@@ -208,14 +208,18 @@ def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_
             "ms": ms.value, "records": rec.value, "Grecords_per_s": rec.value / ms.value / 1e6}
 
 
+VALU_KINDS = ("v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cmp+v_cndmask_b32(vcc)", "v_max3_f32", "v_add_f32", "v_mul_f32", "v_cndmask_b32_e64(sgpr pair)",
+              "s_mov vcc+v_cndmask_b32(vcc)", "v_cmp_lt_f32", "v_min_f32", "v_mov_b32", "v_pk_add_f32", "v_rcp_f32", "mix(fma,cnd,pk_mul,cnd,max3,pk_add,add,cnd)", "v_and_b32")
+
+
 def microbench_valu(kind=0, waves_per_simd=4, iters=20000, lane_mask=(1 << 64) - 1, device=0):
     """VALU issue calibration (include/dsrt.h): {"ms", "wave_instructions", "cycles_per_instruction_per_simd", ...}."""
-    ms, n, cyc = C.c_float(), C.c_double(), C.c_double()
-    _check(lib.dsrt_microbench_valu(int(device), int(kind), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(cyc)),
+    ms, n, cyc, ghz = C.c_float(), C.c_double(), C.c_double(), C.c_double()
+    _check(lib.dsrt_microbench_valu(int(device), int(kind), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(cyc), C.byref(ghz)),
            "dsrt_microbench_valu")
-    return {"kind": ("v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cndmask_b32", "v_max3_f32")[kind], "waves_per_simd": waves_per_simd, "iters": iters,
+    return {"kind": VALU_KINDS[kind], "waves_per_simd": waves_per_simd, "iters": iters,
             "lanes": bin(lane_mask).count("1"), "lane_mask": hex(lane_mask), "ms": ms.value, "wave_instructions": n.value,
-            "G_wave_instructions_per_s": n.value / ms.value / 1e6, "cycles_per_instruction_per_simd": cyc.value}
+            "G_wave_instructions_per_s": n.value / ms.value / 1e6, "memtime_ticks_per_instruction_per_simd": cyc.value, "memtime_GHz": ghz.value}
 
 
 def stats_dict(st):
@@ -298,6 +302,13 @@ class Context:
         ours, theirs = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         _check(lib.dsrt_selftest_philox(self._h, int(seed), int(subsequence), int(n), ours.ctypes.data, theirs.ctypes.data), "dsrt_selftest_philox")
         return ours, theirs
+
+    def selftest_devkat(self, fn, in12):
+        """dsrt_selftest_devkat: the kernel's material / frame helpers on n x 12 input words -> n x 12 output words (float32 arrays)."""
+        a = np.ascontiguousarray(in12, np.float32).reshape(-1, 12)
+        out = np.zeros_like(a)
+        _check(lib.dsrt_selftest_devkat(self._h, int(fn), a.ctypes.data, out.ctypes.data, int(a.shape[0])), "dsrt_selftest_devkat")
+        return out
 
     def selftest_math(self, fn, x, y=0.0):
         x = np.ascontiguousarray(x, np.float32)

@@ -32,6 +32,7 @@ hipError_t launch_philox(unsigned long long seed, unsigned long long sub, int n,
 hipError_t launch_deinterleave(const uint8_t* gathered, uint8_t* image, int W, int H, int tile, int tiles_x, int shard_count,
                                size_t shard_stride_bytes, hipStream_t stream);
 hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipStream_t stream);
+hipError_t launch_devkat(int fn, const float* in, float* out, int n, hipStream_t stream);
 int kernel_waves_per_block();
 hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_t* cost, uint32_t* order, uint32_t* sched, uint32_t items_per_pixel,
                              uint32_t resident_lanes, bool cull, hipStream_t stream, const BatchFrame* batch = nullptr, uint32_t frames = 1, uint32_t stride = 0);
@@ -798,6 +799,20 @@ int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float*
     HIP_TRY(launch_math(fn, dx.p, y, dy.p, n, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dy.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return DSRT_OK;
+}
+
+int dsrt_selftest_devkat(DsrtContext* ctx, int fn, const float* in12, float* out12, int n) {
+    if (!ctx || !in12 || !out12 || n <= 0 || fn < 0 || fn > 5) { set_error("dsrt_selftest_devkat: bad argument"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<float> di, dout;
+    int rc;
+    if ((rc = di.alloc((size_t)n * 12)) || (rc = dout.alloc((size_t)n * 12))) return rc;
+    HIP_TRY(hipMemcpy(di.p, in12, (size_t)n * 12 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dout.p, 0, (size_t)n * 12 * sizeof(float)));
+    HIP_TRY(launch_devkat(fn, di.p, dout.p, n, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out12, dout.p, (size_t)n * 12 * sizeof(float), hipMemcpyDeviceToHost));
     return DSRT_OK;
 }
 

@@ -97,13 +97,19 @@ __device__ __forceinline__ F3 random_in_unit_sphere(Rng& rng) {   // :82-91
     }
 }
 
-// sample_cosine_hemisphere :121-141 with build_onb :112-118 and random_cosine_direction :99-109
+// build_onb :112-118
+__device__ __forceinline__ void build_onb(F3 n, F3& u, F3& v, F3& w) {
+    w = normalize(n);
+    F3 a = (fabsf(w.x) > 0.9f) ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+    v = normalize(cross(w, a));
+    u = cross(v, w);
+}
+
+// sample_cosine_hemisphere :121-141 with random_cosine_direction :99-109
 template <class Rng>
 __device__ __forceinline__ F3 sample_cosine_hemisphere(F3 normal, Rng& rng, float& pdf) {
-    F3 w = normalize(normal);
-    F3 a = (fabsf(w.x) > 0.9f) ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-    F3 v = normalize(cross(w, a));
-    F3 u = cross(v, w);
+    F3 u, v, w;
+    build_onb(normal, u, v, w);
     float r1 = rand01(rng);
     float r2 = rand01(rng);
     float lz = sqrtf(1.0f - r2);
@@ -151,6 +157,31 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) {         
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
     r0 = r0 * r0;
     return r0 + (1.0f - r0) * dsrt_powf(1.0f - cosine, 5.0f);
+}
+
+// scatter_metal :603-619: the scattered direction; returns whether the ray goes on (false: absorbed, the path ends).
+template <class Rng>
+__device__ __forceinline__ bool scatter_metal(F3 rd, F3 hn, float mat_fuzz, Rng& rng, F3& dir) {
+    const F3 refl = reflect(normalize(rd), hn);
+    const float fuzz = fmaxf(0.0f, fminf(1.0f, mat_fuzz));
+    dir = refl + (random_in_unit_sphere(rng) * fuzz);
+    return dot(dir, hn) > 0.0f;
+}
+
+// scatter_dielectric :621-661: the scattered direction (no attenuation; always goes on).  The random number is drawn only when the ray
+// CAN refract (`||` short-circuits, as in the reference).
+template <class Rng>
+__device__ __forceinline__ F3 scatter_dielectric(F3 rd, F3 hn, bool front, float ref_idx, Rng& rng) {
+    float eta = ref_idx;
+    if (eta <= 0.0f || !isfinite(eta)) eta = 1.5f;
+    const float ratio = front ? (1.0f / eta) : eta;
+    const F3 unit = normalize(rd);
+    const float cos_t = fminf(dot(unit * -1.0f, hn), 1.0f);
+    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    const bool cannot = ratio * sin_t > 1.0f;
+    const float rprob = schlick(cos_t, ratio);
+    if (cannot || rprob > rand01(rng)) return reflect(unit, hn);
+    return refract(unit, hn, ratio);
 }
 
 // One box of bbox_hit :285-315 against a ray whose 1/dir is hoisted (same division, done once per ray).

@@ -109,18 +109,29 @@ gather_kernel(const float4* __restrict__ table, uint32_t n_rec, int iters, int l
 // ---------------------------------------------------------------------------------------------------------------
 // The vector-ALU ISSUE ceiling (dsrt_microbench_valu).  The render kernel is bound by VALU issue, so the ceiling it is priced against
 // has to be measured, not assumed: `waves_per_simd` waves on every SIMD of the chip each run `iters` x 32 instructions of ONE kind
-// from EIGHT INDEPENDENT accumulator streams (no instruction reads the result of any of the seven before it), written as inline
-// assembly so that the instruction counted is the instruction issued.  Every wave times itself with the shader-clock counter
-// (s_memtime); cycles per wave-instruction per SIMD = mean wave time / (waves_per_simd * instructions per wave).
-//   kind 0  v_fma_f32        kind 1  v_pk_fma_f32 (two fp32 results per lane)      kind 2  v_pk_mul_f32
-//   kind 3  v_cndmask_b32 (reads vcc)                                              kind 4  v_max3_f32
+// from EIGHT INDEPENDENT register streams (no instruction reads the result of any of the seven before it), written as inline
+// assembly so that the instruction counted is the instruction issued.  The launch carries enough dynamic LDS per workgroup that
+// exactly `waves_per_simd` workgroups fit a CU, so the grid of CUs x waves_per_simd workgroups is spread evenly whatever the
+// dispatcher's order.  Every wave stamps its loop with the shader-clock counter (s_memtime) and the 100 MHz wall clock
+// (s_memrealtime); the host reports instructions per second, cycles per wave-instruction per SIMD by those stamps, and the
+// frequency the s_memtime counter ran at.  The PMC route (SQ_INSTS_VALU over GRBM_GUI_ACTIVE) is tools/valu_pmc.sh.
+//   kind  0 v_fma_f32          1 v_pk_fma_f32            2 v_pk_mul_f32        3 v_cmp + 32 x v_cndmask_b32 (vcc)    4 v_max3_f32
+//         5 v_add_f32          6 v_mul_f32               7 v_cndmask_b32_e64 (mask in an SGPR pair)
+//         8 v_cndmask_b32 (vcc set by s_mov)             9 v_cmp_lt_f32 vcc   10 v_min_f32         11 v_mov_b32      12 v_pk_add_f32
+//        13 v_rcp_f32         14 a mix: fma, cndmask, pk_mul, cndmask, max3, pk_add, add, cndmask                    15 v_and_b32
 // `lane_mask`: the lanes of every wave that execute the loop (the rest branch around it): does a half-empty wave issue faster?
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v2f_mb __attribute__((ext_vector_type(2)));
+constexpr int kValuKinds = 16;
+
+#define DSRT_R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define DSRT_R32(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP)
+#define DSRT_SCALAR_ASM(PRE, OP) asm volatile(PRE DSRT_R32(OP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c), "s"(smask) : "vcc")
+#define DSRT_PAIR_ASM(OP) asm volatile(DSRT_R32(OP) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc))
 
 template <int KIND>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
-valu_kernel(int iters, unsigned long long lane_mask, unsigned long long* __restrict__ wave_cycles, float* __restrict__ sink) {
+valu_kernel(int iters, unsigned long long lane_mask, unsigned long long smask, unsigned long long* __restrict__ stamps, float* __restrict__ sink) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const float seed = (float)(threadIdx.x & 7u) * 1e-3f;
@@ -128,39 +139,98 @@ valu_kernel(int iters, unsigned long long lane_mask, unsigned long long* __restr
     v2f_mb p0 = {a0, a1}, p1 = {a1, a2}, p2 = {a2, a3}, p3 = {a3, a4}, p4 = {a4, a5}, p5 = {a5, a6}, p6 = {a6, a7}, p7 = {a7, a0};
     const float m = 0.99999994f, c = 1e-7f;
     const v2f_mb pm = {m, m}, pc = {c, c};
-    unsigned long long t0 = 0, t1 = 0;
+    unsigned long long t0 = 0, t1 = 0, r0 = 0, r1 = 0;
     if ((lane_mask >> lane) & 1ull) {
+        r0 = __builtin_amdgcn_s_memrealtime();
         t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
-#define DSRT_R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
             if (KIND == 0) {
-#define DSRT_FMA(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
-                asm volatile(DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA) DSRT_R8(DSRT_FMA)
-                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+#define DSRT_OP(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
             } else if (KIND == 1) {
-#define DSRT_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
-                asm volatile(DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA) DSRT_R8(DSRT_PKFMA)
-                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc));
+#define DSRT_OP(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
+                DSRT_PAIR_ASM(DSRT_OP);
+#undef DSRT_OP
             } else if (KIND == 2) {
-#define DSRT_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n\t"
-                asm volatile(DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL) DSRT_R8(DSRT_PKMUL)
-                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm));
+#define DSRT_OP(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n\t"
+                DSRT_PAIR_ASM(DSRT_OP);
+#undef DSRT_OP
             } else if (KIND == 3) {
-#define DSRT_CND(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
-                asm volatile("v_cmp_gt_f32 vcc, %8, %9\n\t" DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND) DSRT_R8(DSRT_CND)
-                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c) : "vcc");
+#define DSRT_OP(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
+                DSRT_SCALAR_ASM("v_cmp_gt_f32 vcc, %8, %9\n\t", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 4) {
+#define DSRT_OP(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 5) {
+#define DSRT_OP(i) "v_add_f32 %" #i ", %" #i ", %9\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 6) {
+#define DSRT_OP(i) "v_mul_f32 %" #i ", %" #i ", %8\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 7) {
+#define DSRT_OP(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, %10\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 8) {
+#define DSRT_OP(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
+                DSRT_SCALAR_ASM("s_mov_b64 vcc, %10\n\t", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 9) {
+#define DSRT_OP(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 10) {
+#define DSRT_OP(i) "v_min_f32 %" #i ", %" #i ", %8\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 11) {
+#define DSRT_OP(i) "v_mov_b32 %" #i ", %8\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 12) {
+#define DSRT_OP(i) "v_pk_add_f32 %" #i ", %" #i ", %9\n\t"
+                DSRT_PAIR_ASM(DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 13) {
+#define DSRT_OP(i) "v_rcp_f32 %" #i ", %" #i "\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
+            } else if (KIND == 14) {
+#define DSRT_MIX "v_fma_f32 %0, %0, %8, %9\n\tv_cndmask_b32_e64 %1, %1, %8, %12\n\tv_pk_mul_f32 %4, %4, %10\n\tv_cndmask_b32_e64 %2, %2, %8, %12\n\t" \
+                 "v_max3_f32 %3, %3, %8, %9\n\tv_pk_add_f32 %5, %5, %11\n\tv_add_f32 %0, %0, %9\n\tv_cndmask_b32_e64 %1, %1, %9, %12\n\t"
+                asm volatile(DSRT_MIX DSRT_MIX DSRT_MIX DSRT_MIX
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(m), "v"(c), "v"(pm), "v"(pc), "s"(smask));
+#undef DSRT_MIX
             } else {
-#define DSRT_MAX3(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n\t"
-                asm volatile(DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3) DSRT_R8(DSRT_MAX3)
-                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+#define DSRT_OP(i) "v_and_b32 %" #i ", %" #i ", %8\n\t"
+                DSRT_SCALAR_ASM("", DSRT_OP);
+#undef DSRT_OP
             }
         }
         t1 = __builtin_readcyclecounter();
+        r1 = __builtin_amdgcn_s_memrealtime();
     }
-    const unsigned long long first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(lane_mask));
-    if (lane == (uint32_t)first) wave_cycles[gwave] = t1 - t0;
+    const uint32_t first = (uint32_t)__builtin_ctzll(lane_mask);
+    if (lane == first) { stamps[2 * (size_t)gwave] = t1 - t0; stamps[2 * (size_t)gwave + 1] = r1 - r0; }
     const float r = (((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7))) + (((p0.x + p1.y) + (p2.x + p3.y)) + ((p4.x + p5.y) + (p6.x + p7.y)));
     if (r == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int KIND>
+hipError_t launch_valu(int kind, int blocks, size_t lds, int iters, unsigned long long lane_mask, unsigned long long* stamps, float* sink) {
+    if (kind == KIND) {
+        hipError_t e = hipFuncSetAttribute((const void*)valu_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(valu_kernel<KIND>, dim3(blocks), dim3(256), lds, nullptr, iters, lane_mask, 0x5A5A5A5AA5A5A5A5ull, stamps, sink);
+        return hipGetLastError();
+    }
+    if constexpr (KIND + 1 < kValuKinds) return launch_valu<KIND + 1>(kind, blocks, lds, iters, lane_mask, stamps, sink);
+    return hipErrorInvalidValue;
 }
 
 template <int MODE>
@@ -236,17 +306,17 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
 }
 
 extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
-                                    double* out_cycles_per_instruction_per_simd) {
-    if (kind < 0 || kind > 4 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms || !out_wave_instructions ||
-        !out_cycles_per_instruction_per_simd) {
+                                    double* out_cycles_per_instruction_per_simd, double* out_counter_GHz) {
+    if (kind < 0 || kind >= kValuKinds || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms || !out_wave_instructions ||
+        !out_cycles_per_instruction_per_simd || !out_counter_GHz) {
         dsrt::set_error("dsrt_microbench_valu: bad argument");
         return DSRT_ERR_INVALID;
     }
-    unsigned long long* cycles = nullptr;
+    unsigned long long* stamps = nullptr;
     float* sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        if (cycles) (void)hipFree(cycles);
+        if (stamps) (void)hipFree(stamps);
         if (sink) (void)hipFree(sink);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -254,36 +324,29 @@ extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, in
     MB_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     MB_TRY(hipGetDeviceProperties(&prop, device));
-    const int blocks = prop.multiProcessorCount * waves_per_simd;          // 256 threads = one wave per SIMD of a CU per block
+    const int blocks = prop.multiProcessorCount * waves_per_simd;          // 256 threads = one wave per SIMD of a CU per workgroup
+    // dynamic LDS per workgroup such that waves_per_simd workgroups fit a CU's 160 KB and one more does not
+    const size_t lds = ((size_t)160 * 1024 / (size_t)waves_per_simd) / 1024 * 1024 - (waves_per_simd == 8 ? 0 : 1024);
     const size_t waves = (size_t)blocks * 4;
-    MB_TRY(hipMalloc((void**)&cycles, waves * sizeof(unsigned long long)));
+    MB_TRY(hipMalloc((void**)&stamps, 2 * waves * sizeof(unsigned long long)));
     MB_TRY(hipMalloc((void**)&sink, waves * 64 * sizeof(float)));
     MB_TRY(hipEventCreate(&e0));
     MB_TRY(hipEventCreate(&e1));
-    auto run = [&](int n) -> hipError_t {
-        switch (kind) {
-            case 0: hipLaunchKernelGGL(valu_kernel<0>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
-            case 1: hipLaunchKernelGGL(valu_kernel<1>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
-            case 2: hipLaunchKernelGGL(valu_kernel<2>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
-            case 3: hipLaunchKernelGGL(valu_kernel<3>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
-            default: hipLaunchKernelGGL(valu_kernel<4>, dim3(blocks), dim3(256), 0, nullptr, n, (unsigned long long)lane_mask, cycles, sink); break;
-        }
-        return hipGetLastError();
-    };
-    MB_TRY(run(iters < 256 ? iters : 256));
+    MB_TRY(launch_valu<0>(kind, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));      // warms the clocks as well: same length as the timed run
     MB_TRY(hipDeviceSynchronize());
     MB_TRY(hipEventRecord(e0, nullptr));
-    MB_TRY(run(iters));
+    MB_TRY(launch_valu<0>(kind, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));
     MB_TRY(hipEventRecord(e1, nullptr));
     MB_TRY(hipEventSynchronize(e1));
     MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
-    std::vector<unsigned long long> host(waves);
-    MB_TRY(hipMemcpy(host.data(), cycles, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum = 0;
-    for (unsigned long long c : host) sum += (double)c;
-    const double per_wave = (double)iters * (kind == 3 ? 33.0 : 32.0);
+    std::vector<unsigned long long> host(2 * waves);
+    MB_TRY(hipMemcpy(host.data(), stamps, 2 * waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    for (size_t w = 0; w < waves; ++w) { cyc += (double)host[2 * w]; real += (double)host[2 * w + 1]; }
+    const double per_wave = (double)iters * (kind == 3 || kind == 8 ? 33.0 : 32.0);
     *out_wave_instructions = per_wave * (double)waves;
-    *out_cycles_per_instruction_per_simd = (sum / (double)waves) / ((double)waves_per_simd * per_wave);
+    *out_cycles_per_instruction_per_simd = (cyc / (double)waves) / ((double)waves_per_simd * per_wave);
+    *out_counter_GHz = real > 0 ? cyc / real * 0.1 : 0.0;                  // s_memrealtime ticks at 100 MHz
     cleanup();
     return DSRT_OK;
 }

@@ -243,25 +243,13 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     albedo = albedo * tex2d(S, tex_id, u_tex, v_tex, c[C_TEX_FETCHES]);
                 }
                 if (mtype == MAT_DIELECTRIC) {                                               // scatter_dielectric :621-661
-                    float eta = m2.w;
-                    if (eta <= 0.0f || !isfinite(eta)) eta = 1.5f;
-                    const float ratio = front ? (1.0f / eta) : eta;
-                    const F3 unit = normalize(rd);
-                    const float cos_t = fminf(dot(unit * -1.0f, hn), 1.0f);
-                    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
-                    const bool cannot = ratio * sin_t > 1.0f;
-                    const float rprob = schlick(cos_t, ratio);
-                    F3 dir;
-                    if (cannot || rprob > rand01(rng)) dir = reflect(unit, hn);
-                    else dir = refract(unit, hn, ratio);
+                    const F3 dir = scatter_dielectric(rd, hn, front, m2.w, rng);
                     ro = hp; rd = dir;                      // attenuation is (1,1,1): throughput unchanged
                     depth++;
                     state = ST_BOUNCE;
                 } else if (mtype == MAT_METAL) {                                             // scatter_metal :603-619
-                    const F3 refl = reflect(normalize(rd), hn);
-                    const float fuzz = fmaxf(0.0f, fminf(1.0f, m2.z));
-                    const F3 dir = refl + (random_in_unit_sphere(rng) * fuzz);
-                    if (dot(dir, hn) > 0.0f) {
+                    F3 dir;
+                    if (scatter_metal(rd, hn, m2.z, rng, dir)) {
                         thr = thr * albedo;
                         ro = hp; rd = dir;
                         depth++;

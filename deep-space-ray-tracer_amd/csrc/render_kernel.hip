@@ -531,6 +531,34 @@ __global__ void dsrt_math_kernel(int fn, const float* __restrict__ x, float y, f
     out[i] = fn == 0 ? dsrt_sinf(x[i]) : (fn == 1 ? dsrt_cosf(x[i]) : dsrt_powf(x[i], y));
 }
 
+// Test hook (dsrt_selftest_devkat): the render kernel's own material / frame helpers of device_math.h on explicit inputs, 12 words in and
+// 12 words out per case, so that they can be compared with known answers produced by the reference's host code (tests/golden/ref_matkat.json).
+//   fn 0 reflect            in: v[3] n[3]                              out: r[3]
+//   fn 1 refract            in: v[3] n[3] eta                          out: r[3]
+//   fn 2 scatter_metal      in: dir[3] n[3] fuzz, LCG state (bits)     out: dir[3], went on (1.0 / 0.0), LCG state after (bits)
+//   fn 3 scatter_dielectric in: dir[3] n[3] ref_idx, state, front face out: dir[3], -, LCG state after (bits)
+//   fn 4 build_onb          in: n[3]                                   out: u[3] v[3] w[3]
+//   fn 5 schlick            in: cosine, ratio                          out: reflectance
+__global__ void dsrt_devkat_kernel(int fn, const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * 12;
+    float* o = out + (size_t)i * 12;
+    const F3 v = ld3(a), nn = ld3(a + 3);
+    uint32_t rng = __float_as_uint(a[7]);
+    if (fn == 0) { const F3 r = reflect(v, nn); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+    else if (fn == 1) { const F3 r = refract(v, nn, a[6]); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+    else if (fn == 2) { F3 d; const bool ok = scatter_metal(v, nn, a[6], rng, d); o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = ok ? 1.0f : 0.0f; o[4] = __uint_as_float(rng); }
+    else if (fn == 3) { const F3 d = scatter_dielectric(v, nn, __float_as_uint(a[8]) != 0u, a[6], rng); o[0] = d.x; o[1] = d.y; o[2] = d.z; o[4] = __uint_as_float(rng); }
+    else if (fn == 4) { F3 u, vv, w; build_onb(v, u, vv, w); o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = vv.x; o[4] = vv.y; o[5] = vv.z; o[6] = w.x; o[7] = w.y; o[8] = w.z; }
+    else { o[0] = schlick(a[0], a[1]); }
+}
+
+hipError_t launch_devkat(int fn, const float* in, float* out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(dsrt_devkat_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, fn, in, out, n);
+    return hipGetLastError();
+}
+
 // rng_mode 1: a pixel's samples were summed as integers in units of 2^-20 (path_machine.h, end_sample); here the mean, the
 // reference's tone map and the 8-bit store (:1003-1030).  Pixels nobody sampled (culled tiles, padding) hold zero sums: black.
 __global__ void dsrt_resolve_kernel(const unsigned long long* __restrict__ sums, int spp, float inv_gamma, size_t n_pixels,

@@ -279,6 +279,12 @@ int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h
  * fn 0 = sin, 1 = cos, 2 = pow(x[i], y).  Host pointers. */
 int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n);
 
+/* Device evaluation of the render kernel's own material / frame helpers (csrc/device_math.h: reflect, refract, scatter_metal,
+ * scatter_dielectric, build_onb, schlick -- src/gpu_render.cu:112-118, 195-212, 603-661) on explicit inputs, for comparison with known
+ * answers produced by the reference's host code (tests/golden/ref_matkat.json).  12 words in and 12 words out per case, host pointers;
+ * the packing per `fn` (0..5) is documented at dsrt_devkat_kernel in csrc/render_kernel.hip. */
+int dsrt_selftest_devkat(DsrtContext* ctx, int fn, const float* in12, float* out12, int n);
+
 /* Device check that the kernel's stateless Philox4x32-10 equals rocRAND's engine: the first n 32-bit words of
  * (seed, subsequence, offset 0) from both.  Host pointers. */
 int dsrt_selftest_philox(DsrtContext* ctx, uint64_t seed, uint64_t subsequence, int n, uint32_t* ours, uint32_t* rocrand_words);
@@ -325,11 +331,12 @@ int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, 
                            float* out_ms, double* out_records);
 
 /* The other calibration: the vector-ALU issue ceiling.  `waves_per_simd` (1..8) waves on every SIMD of the chip each issue iters x 32
- * instructions of one kind from eight independent streams (kind 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul_f32, 3 v_cndmask_b32, 4 v_max3_f32);
- * only the lanes in `lane_mask` execute them.  Returns the kernel time, the wave-instructions issued, and the shader cycles per
- * wave-instruction per SIMD from the waves' own cycle counters.  No reference interface: measurement only. */
+ * instructions of one kind from eight independent register streams (kinds 0..15: v_fma_f32, v_pk_fma_f32, v_pk_mul_f32, v_cndmask_b32, ... and a
+ * mix; the list is at valu_kernel in csrc/microbench.hip); only the lanes in `lane_mask` execute them.  Returns the kernel time (HIP events),
+ * the wave-instructions issued, and from the waves' own stamps the s_memtime ticks per wave-instruction per SIMD and the frequency that
+ * counter ran at (against the 100 MHz s_memrealtime).  No reference interface: measurement only. */
 int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
-                         double* out_cycles_per_instruction_per_simd);
+                         double* out_cycles_per_instruction_per_simd, double* out_counter_GHz);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

@@ -603,6 +603,48 @@ void dsrt_oracle_camera_ray(const GPUCamera* cam, int px, int py, int W, int H, 
     orig[0] = r.orig.x; orig[1] = r.orig.y; orig[2] = r.orig.z; dir[0] = r.dir.x; dir[1] = r.dir.y; dir[2] = r.dir.z;
 }
 
+/* Test hooks for the known answers of the reference's material / frame helpers (tests/golden/ref_matkat.json): the functions ray_color's
+ * specular branches and the cosine sampler are made of, called exactly as ray_color calls them. */
+void dsrt_oracle_reflect(const float v[3], const float n[3], float out[3]) {
+    V3 r = reflect(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void dsrt_oracle_refract(const float v[3], const float n[3], float eta, float out[3]) {
+    V3 r = refract(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]), eta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void dsrt_oracle_normalize(const float v[3], float out[3]) {
+    V3 r = norm(v3(v[0], v[1], v[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+int dsrt_oracle_scatter_metal(const float dir[3], const float n[3], float fuzz, uint32_t* state, float out_dir[3]) {
+    DsrtOracleCounters c; memset(&c, 0, sizeof c);
+    Rng g = { *state, &c };
+    GPUMaterial m; memset(&m, 0, sizeof m); m.fuzz = fuzz;
+    Ray in = { v3(0, 0, 0), v3(dir[0], dir[1], dir[2]) }, sc;
+    Hit rec; memset(&rec, 0, sizeof rec); rec.normal = v3(n[0], n[1], n[2]);
+    V3 att;
+    const int ok = scatter_metal(&m, &in, &rec, &g, &sc, &att, v3(1, 1, 1));
+    *state = g.state; out_dir[0] = sc.dir.x; out_dir[1] = sc.dir.y; out_dir[2] = sc.dir.z;
+    return ok;
+}
+void dsrt_oracle_scatter_dielectric(const float dir[3], const float n[3], int front_face, float ref_idx, uint32_t* state, float out_dir[3]) {
+    DsrtOracleCounters c; memset(&c, 0, sizeof c);
+    Rng g = { *state, &c };
+    GPUMaterial m; memset(&m, 0, sizeof m); m.ref_idx = ref_idx;
+    Ray in = { v3(0, 0, 0), v3(dir[0], dir[1], dir[2]) }, sc;
+    Hit rec; memset(&rec, 0, sizeof rec); rec.normal = v3(n[0], n[1], n[2]); rec.front_face = front_face;
+    V3 att;
+    (void)scatter_dielectric(&m, &in, &rec, &g, &sc, &att);
+    *state = g.state; out_dir[0] = sc.dir.x; out_dir[1] = sc.dir.y; out_dir[2] = sc.dir.z;
+}
+void dsrt_oracle_build_onb(const float n[3], float u[3], float v[3], float w[3]) {
+    V3 uu, vv, ww;
+    build_onb(v3(n[0], n[1], n[2]), &uu, &vv, &ww);
+    u[0] = uu.x; u[1] = uu.y; u[2] = uu.z; v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; w[0] = ww.x; w[1] = ww.y; w[2] = ww.z;
+}
+float dsrt_oracle_schlick(float cosine, float ref_idx) { return schlick(cosine, ref_idx); }
+
 float dsrt_oracle_sinf(float x) { return dsrt_sinf(x); }
 float dsrt_oracle_cosf(float x) { return dsrt_cosf(x); }
 float dsrt_oracle_powf(float x, float y) { return dsrt_powf(x, y); }

@@ -22,11 +22,20 @@
  *       * rand01, the rejection loop of random_in_unit_sphere, the local cosine direction and the
  *         camera-ray set-up against the reference's own host-compilable DEVICE helpers, executed
  *         (inc/rtweekend.h:126-202, inc/camera.h:35-61; tests/golden/ref_devkat.json): bit for bit where
- *         the arithmetic is float or exact, to 4e-7 where the helper computes in double.
- *   - What remains **parity unpinned** against an execution of the reference: ray_color's control flow
- *     (:715-936: Russian roulette, sun NEE, the mixture branch, the per-sample clamp), scene_hit's
- *     combination of BVH and spheres (:509-551) and the traversal ORDER of bvh_hit_closest (:387-473,
- *     which decides equal-distance ties).  These are a line-by-line restatement checked by review.
+ *         the arithmetic is float or exact, to 4e-7 where the helper computes in double;
+ *       * reflect, refract, scatter_metal (fuzz 0: direction and accept test), scatter_dielectric on the
+ *         total-internal-reflection branch (direction, and that no random number is drawn), build_onb
+ *         and schlick against the reference's host helpers and material classes, executed (inc/vec3.h:136-147,
+ *         inc/material.h:28-32, 123-180, inc/onb.h:47-56; tests/golden/ref_matkat.json): bit for bit where
+ *         the host arithmetic is float (everything but reflectance, which is double: to 3e-7); build_onb's u
+ *         is the exact negative of the class's (cross(v, w) against cross(w, v)).
+ *   - What remains **parity unpinned** against an execution of the reference is CONTROL FLOW AND ORDER ONLY:
+ *     ray_color's sequence of decisions (:715-936: Russian roulette, sun NEE, the mixture branch, the
+ *     per-sample clamp, which helper is called when and how many draws it takes), scene_hit's combination
+ *     of BVH and spheres (:509-551) and the traversal ORDER of bvh_hit_closest (:387-473, which decides
+ *     equal-distance ties).  Every arithmetic leaf those call is pinned above.  The control flow is a
+ *     line-by-line restatement checked by review; src/gpu_render.cu needs nvcc and libcudart, which this
+ *     image does not have, and no stand-in is written for them.
  *   - cosf/sinf/powf come from include/dsrt_detmath.h (shared with the HIP kernel), not from any
  *     libm: see that header.  Build with -DDSRT_ORACLE_LIBM to use the host libm instead (for the
  *     statistical comparison only).
@@ -86,6 +95,17 @@ int dsrt_oracle_bbox_hit(const float lo[3], const float hi[3], const float orig[
 void dsrt_oracle_random_in_unit_sphere(uint32_t* state, float out[3]);
 void dsrt_oracle_random_cosine_direction(uint32_t* state, float out[3]);
 void dsrt_oracle_camera_ray(const GPUCamera* cam, int px, int py, int W, int H, float jx, float jy, float orig[3], float dir[3]);
+
+/* reflect :195, refract :199-206 (normalises its argument first), f3_norm :51-56, scatter_metal :603-619 (returns "goes on"),
+ * scatter_dielectric :621-661, build_onb :112-118, schlick :208-212 on their own, for the known answers produced by the reference's host
+ * helpers and material classes (inc/vec3.h:136-147, inc/material.h:28-32, 123-180, inc/onb.h:47-56; tests/golden/ref_matkat.json). */
+void dsrt_oracle_reflect(const float v[3], const float n[3], float out[3]);
+void dsrt_oracle_refract(const float v[3], const float n[3], float eta, float out[3]);
+void dsrt_oracle_normalize(const float v[3], float out[3]);
+int  dsrt_oracle_scatter_metal(const float dir[3], const float n[3], float fuzz, uint32_t* state, float out_dir[3]);
+void dsrt_oracle_scatter_dielectric(const float dir[3], const float n[3], int front_face, float ref_idx, uint32_t* state, float out_dir[3]);
+void dsrt_oracle_build_onb(const float n[3], float u[3], float v[3], float w[3]);
+float dsrt_oracle_schlick(float cosine, float ref_idx);
 
 float dsrt_oracle_sinf(float x);
 float dsrt_oracle_cosf(float x);

@@ -16,6 +16,8 @@
 //                              only functions needing libcudart, are never referenced and are dropped by
 //                              --gc-sections)
 //   inc/aabb.h, sphere.h, triangle.h, hittable_list.h    the CPU hit classes, for ray-level cross-checks
+//   inc/vec3.h reflect / refract :136-147, inc/material.h reflectance :28-32, metal::scatter :123-137,
+//   dielectric::scatter :153-180, inc/onb.h build_from_w :47-56     material / frame known answers (cmd_matkat)
 //
 // NOT exercised, because it cannot be built here: src/gpu_render.cu (the CUDA kernel).
 
@@ -281,6 +283,105 @@ static int cmd_devkat(int n) {
     return 0;
 }
 
+// Known answers from the reference's MATERIAL and FRAME helpers, executed: the host counterparts of what ray_color's specular branches and
+// the cosine sampler are made of (src/gpu_render.cu:112-118, 195-212, 603-661).  vec3 is float-based (inc/vec3.h:14-70: unit_vector is
+// `v * (1.0f / length)`, like the kernel's f3_norm), so wherever the helper's own arithmetic is float the answers are bit patterns:
+//   reflect                 inc/vec3.h:136-139      float: bit for bit
+//   refract                 inc/vec3.h:141-147      float: bit for bit (the kernel's copy re-normalises its argument first, :199-206;
+//                                                   inputs here come out of unit_vector, the test compares where that is idempotent)
+//   metal::scatter, fuzz 0  inc/material.h:123-137  reflect(unit_vector(dir), n) + 0.0f * (a rand() vector): the direction and the
+//                                                   accept test dot(dir, n) > 0
+//   dielectric::scatter     inc/material.h:153-180  on the total-internal-reflection branch only (the decision is taken in double there:
+//                                                   cases keep ratio * sin_theta at least 5 % above 1; the other branch draws rand());
+//                                                   what is pinned: the direction, and that NO random number is drawn
+//   reflectance             inc/material.h:28-32    Schlick in double: the kernel's float copy to rounding
+//   onb::build_from_w       inc/onb.h:47-56         w and v bit for bit; u = cross(w, v) is the NEGATIVE of the kernel's cross(v, w)
+static int cmd_matkat(int n) {
+    uint32_t s = 4242u;
+    auto sgn = [&](float m) { return (lcg01(s) * 2.0f - 1.0f) * m; };
+    std::printf("{\"reflect\": [\n");
+    for (int i = 0; i < n; ++i) {
+        const vec3 v(sgn(3.0f), sgn(3.0f), sgn(3.0f));
+        const vec3 nn = unit_vector(vec3(sgn(1.0f), sgn(1.0f), sgn(1.0f) + 1e-3f));
+        const vec3 r = reflect(v, nn);
+        std::printf("  {\"v\": [%u, %u, %u], \"n\": [%u, %u, %u], \"out\": [%u, %u, %u]}%s\n", fbits(v.x()), fbits(v.y()), fbits(v.z()), fbits(nn.x()), fbits(nn.y()),
+                    fbits(nn.z()), fbits(r.x()), fbits(r.y()), fbits(r.z()), i + 1 < n ? "," : "");
+    }
+    std::printf("],\n\"refract\": [\n");
+    const float etas[6] = {1.0f / 1.5f, 1.5f, 1.0f / 1.33f, 1.0f, 2.4f, 1.0f / 2.4f};
+    for (int i = 0; i < n; ++i) {
+        const vec3 uv = unit_vector(vec3(sgn(1.0f), sgn(1.0f), sgn(1.0f) + 1e-3f));
+        vec3 nn = unit_vector(vec3(sgn(1.0f), sgn(1.0f), sgn(1.0f) + 1e-3f));
+        if (dot(uv, nn) > 0.0f) nn = -nn;                                  // the normal faces the incoming ray, as set_face_normal leaves it
+        const float eta = etas[i % 6];
+        const vec3 r = refract(uv, nn, eta);
+        std::printf("  {\"uv\": [%u, %u, %u], \"n\": [%u, %u, %u], \"eta\": %u, \"out\": [%u, %u, %u]}%s\n", fbits(uv.x()), fbits(uv.y()), fbits(uv.z()), fbits(nn.x()),
+                    fbits(nn.y()), fbits(nn.z()), fbits(eta), fbits(r.x()), fbits(r.y()), fbits(r.z()), i + 1 < n ? "," : "");
+    }
+    std::printf("],\n\"metal_fuzz0\": [\n");
+    {
+        metal m(color(0.8f, 0.6f, 0.2f), 0.0);
+        for (int i = 0; i < n; ++i) {
+            const vec3 d(sgn(40.0f), sgn(40.0f), sgn(40.0f));              // ray directions are NOT unit length in this renderer (camera rays: |dir| = focus distance)
+            const vec3 nn = unit_vector(vec3(sgn(1.0f), sgn(1.0f), sgn(1.0f) + 1e-3f));      // either side: the accept test must see both signs
+            hit_record rec;
+            rec.p = point3(sgn(5.0f), sgn(5.0f), sgn(5.0f));
+            rec.normal = nn;
+            scatter_record srec;
+            const bool ok = m.scatter(ray(point3(0, 0, 0), d), rec, srec);
+            const vec3 o = srec.specular_ray.direction();
+            std::printf("  {\"dir\": [%u, %u, %u], \"n\": [%u, %u, %u], \"out\": [%u, %u, %u], \"ok\": %d}%s\n", fbits(d.x()), fbits(d.y()), fbits(d.z()), fbits(nn.x()),
+                        fbits(nn.y()), fbits(nn.z()), fbits(o.x()), fbits(o.y()), fbits(o.z()), ok ? 1 : 0, i + 1 < n ? "," : "");
+        }
+    }
+    std::printf("],\n\"dielectric_tir\": [\n");
+    {
+        int emitted = 0;
+        for (int i = 0; emitted < n && i < 100 * n; ++i) {
+            const bool front = (i & 1) != 0;
+            const double ir = front ? 0.55 : 1.5;                          // ratio = 1 / 0.55 = 1.82 (front face) or 1.5 (leaving the glass)
+            const vec3 d(sgn(40.0f), sgn(40.0f), sgn(40.0f));
+            vec3 nn = unit_vector(vec3(sgn(1.0f), sgn(1.0f), sgn(1.0f) + 1e-3f));
+            const vec3 ud = unit_vector(d);
+            if (dot(ud, nn) > 0.0f) nn = -nn;
+            const double ratio = front ? 1.0 / ir : ir;
+            const double c = fmin((double)dot(-ud, nn), 1.0), sn = std::sqrt(1.0 - c * c);
+            if (!(ratio * sn > 1.05)) continue;                            // well inside the total-internal-reflection regime
+            dielectric g(ir);
+            hit_record rec;
+            rec.p = point3(sgn(5.0f), sgn(5.0f), sgn(5.0f));
+            rec.normal = nn;
+            rec.front_face = front;
+            scatter_record srec;
+            (void)g.scatter(ray(point3(0, 0, 0), d), rec, srec);
+            const vec3 o = srec.specular_ray.direction();
+            const float irf = (float)ir;
+            ++emitted;
+            std::printf("  {\"dir\": [%u, %u, %u], \"n\": [%u, %u, %u], \"front\": %d, \"ref_idx\": %u, \"out\": [%u, %u, %u]}%s\n", fbits(d.x()), fbits(d.y()), fbits(d.z()),
+                        fbits(nn.x()), fbits(nn.y()), fbits(nn.z()), front ? 1 : 0, fbits(irf), fbits(o.x()), fbits(o.y()), fbits(o.z()), emitted < n ? "," : "");
+        }
+    }
+    std::printf("],\n\"reflectance\": [\n");
+    for (int i = 0; i < n; ++i) {
+        const float c = lcg01(s), ratio = etas[i % 6];
+        const double r = reflectance((double)c, (double)ratio);
+        uint64_t rb; std::memcpy(&rb, &r, 8);
+        std::printf("  {\"cos\": %u, \"ratio\": %u, \"out_f64\": %" PRIu64 "}%s\n", fbits(c), fbits(ratio), rb, i + 1 < n ? "," : "");
+    }
+    std::printf("],\n\"onb\": [\n");
+    for (int i = 0; i < n; ++i) {
+        vec3 nn(sgn(2.0f), sgn(2.0f), sgn(2.0f) + 1e-3f);
+        if (i % 5 == 0) nn = vec3(i % 10 ? 1.0f : -1.0f, sgn(0.3f), sgn(0.3f));          // |w.x| > 0.9: the other helper axis
+        onb f;
+        f.build_from_w(nn);
+        std::printf("  {\"n\": [%u, %u, %u], \"u\": [%u, %u, %u], \"v\": [%u, %u, %u], \"w\": [%u, %u, %u]}%s\n", fbits(nn.x()), fbits(nn.y()), fbits(nn.z()),
+                    fbits(f.u().x()), fbits(f.u().y()), fbits(f.u().z()), fbits(f.v().x()), fbits(f.v().y()), fbits(f.v().z()), fbits(f.w().x()), fbits(f.w().y()),
+                    fbits(f.w().z()), i + 1 < n ? "," : "");
+    }
+    std::printf("]}\n");
+    return 0;
+}
+
 // The reference's texture decoder on one file: stbi_load(path, &w, &h, &n, 3), the call of src/gpu_scene_builder.cpp:215
 // (the flip flag of inc/texture.h:133 is a separate, global switch; `flip` sets it like image_texture::load does).
 static int cmd_decode(const char* path, int flip) {
@@ -298,7 +399,7 @@ static int cmd_decode(const char* path, int flip) {
 int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr, "usage: ref_host abi | scene <world.txt> <prefix> | camera fx fy fz ax ay az vfov W H spp depth |"
-                             " poses <pose.txt> W H spp depth vfov | hitkat <n> | devkat <n> | decode <image> [flip]\n");
+                             " poses <pose.txt> W H spp depth vfov | hitkat <n> | devkat <n> | matkat <n> | decode <image> [flip]\n");
         return 2;
     }
     std::string c = argv[1];
@@ -308,6 +409,7 @@ int main(int argc, char** argv) {
     if (c == "poses") return cmd_poses(argc, argv);
     if (c == "hitkat" && argc >= 3) return cmd_hitkat(std::atoi(argv[2]));
     if (c == "devkat" && argc >= 3) return cmd_devkat(std::atoi(argv[2]));
+    if (c == "matkat" && argc >= 3) return cmd_matkat(std::atoi(argv[2]));
     if (c == "decode" && argc >= 3) return cmd_decode(argv[2], argc >= 4 ? std::atoi(argv[3]) : 0);
     return 2;
 }

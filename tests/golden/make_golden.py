@@ -174,7 +174,16 @@ def run_ref(*args, cwd=None):
     return json.loads(out.stdout.decode())
 
 
+def make_matkat():
+    """The reference's material / frame helpers, executed (inc/vec3.h:136-147 reflect / refract, inc/material.h:28-32 reflectance, :123-137
+    metal::scatter at fuzz 0, :153-180 dielectric::scatter on the total-internal-reflection branch, inc/onb.h:47-56 build_from_w)."""
+    json.dump(run_ref("matkat", 64), open(os.path.join(HERE, "ref_matkat.json"), "w"))
+
+
 def main():
+    if "--matkat-only" in sys.argv:
+        make_matkat()
+        return
     if not os.path.exists(REF):
         sys.exit("oracle/_ref/ref_host is missing: run `make -C oracle ref` in the build container")
     make_assets()
@@ -185,6 +194,7 @@ def main():
     json.dump(run_ref("hitkat", 240), open(os.path.join(HERE, "ref_hitkat.json"), "w"))
     # the reference's host-compilable DEVICE helpers (inc/rtweekend.h:126-202, inc/camera.h:35-61): LCG, rejection loop, cosine direction, camera ray
     json.dump(run_ref("devkat", 96), open(os.path.join(HERE, "ref_devkat.json"), "w"))
+    make_matkat()
     cams = []
     for spec in ((-2, 2, 1, 0, 0, -1, 20, 200, 112, 16, 50), (0, 0, 60, 0, 0, 0, 40, 640, 360, 64, 50), (13, 2, 3, 0, 0, -1, 20, 1920, 1080, 1000, 50),
                  (0, 3, 9, 0, 2, 0, 45, 200, 112, 16, 12), (0, 40, 0.001, 0, 0, 0, 35, 320, 240, 4, 5)):

@@ -841,3 +841,65 @@ def test_gather_calibration_kernel_runs(dsrt, gpu_ctx):
     assert all(5.0 < v < 5000.0 for v in rates.values()), rates
     with pytest.raises(dsrt.DsrtError):
         dsrt.microbench_gather(3)
+
+
+class DeviceMatkat:
+    """The render kernel's own helpers (csrc/device_math.h) through dsrt_selftest_devkat: 12 words in, 12 words out per case."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    @staticmethod
+    def _pack(n, **cols):
+        a = np.zeros((n, 12), np.float32)
+        for k, (col, val) in cols.items():
+            val = np.asarray(val)
+            if val.dtype in (np.uint32, np.int32):
+                val = val.astype(np.uint32).view(np.float32)
+            a[:, col:col + (val.shape[1] if val.ndim == 2 else 1)] = val.reshape(n, -1)
+        return a
+
+    def reflect(self, v, n):
+        return self.ctx.selftest_devkat(0, self._pack(len(v), v=(0, v), n=(3, n)))[:, :3]
+
+    def refract(self, v, n, eta):
+        return self.ctx.selftest_devkat(1, self._pack(len(v), v=(0, v), n=(3, n), eta=(6, eta)))[:, :3]
+
+    def metal(self, d, n, fuzz, state):
+        out = self.ctx.selftest_devkat(2, self._pack(len(d), v=(0, d), n=(3, n), fuzz=(6, fuzz), state=(7, state.astype(np.uint32))))
+        return out[:, :3], out[:, 3] != 0.0, out[:, 4].copy().view(np.uint32)
+
+    def dielectric(self, d, n, front, ref_idx, state):
+        out = self.ctx.selftest_devkat(3, self._pack(len(d), v=(0, d), n=(3, n), ref=(6, ref_idx), state=(7, state.astype(np.uint32)), front=(8, front.astype(np.uint32))))
+        return out[:, :3], out[:, 4].copy().view(np.uint32)
+
+    def onb(self, n):
+        out = self.ctx.selftest_devkat(4, self._pack(len(n), v=(0, n)))
+        return out[:, 0:3], out[:, 3:6], out[:, 6:9]
+
+    def schlick(self, cos, ratio):
+        return self.ctx.selftest_devkat(5, self._pack(len(cos), c=(0, cos), r=(1, ratio)))[:, 0]
+
+
+def test_device_material_helpers_match_the_reference_known_answers(dsrt, gpu_ctx, oracle):
+    """The kernel's reflect / refract / scatter_metal / scatter_dielectric / build_onb / schlick (csrc/device_math.h, the functions path_machine.h
+    calls) against what the reference's host code computed (tests/golden/ref_matkat.json), and bit for bit against the oracle's copies."""
+    from test_oracle import OracleMatkat, check_material_known_answers
+    orc = OracleMatkat(oracle)
+    dev = DeviceMatkat(gpu_ctx)
+    check_material_known_answers(dev, orc.normalize)
+    # and, on inputs no golden covers (fuzz > 0: the rejection loop feeds the direction; the refracting branch, which draws): device == oracle, bits
+    rng = np.random.default_rng(5)
+    n = 256
+    d = rng.normal(size=(n, 3)).astype(np.float32) * 30
+    nn = rng.normal(size=(n, 3)).astype(np.float32)
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True).astype(np.float32)
+    fuzz = rng.uniform(-0.2, 1.3, n).astype(np.float32)
+    state = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    a, b = dev.metal(d, nn, fuzz, state), orc.metal(d, nn, fuzz, state)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    front = rng.integers(0, 2, n).astype(np.int32)
+    ref_idx = rng.choice(np.array([1.5, 1.33, 2.4, 0.0, -1.0, np.inf, 0.7], np.float32), n)
+    a, b = dev.dielectric(d, nn, front, ref_idx, state), orc.dielectric(d, nn, front, ref_idx, state)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
+    assert 16 < (b[1] != state).sum() < n                                     # both the drawing and the non-drawing branch occur

@@ -222,3 +222,142 @@ def test_device_helper_known_answers_from_the_reference(oracle):
         o, d = (C.c_float * 3)(), (C.c_float * 3)()
         L.dsrt_oracle_camera_ray(C.byref(cam), row["px"], row["py"], 200, 112, f32(row["jx"]), f32(row["jy"]), o, d)
         assert bits(o) == row["orig"] and bits(d) == row["dir"], row
+
+
+# ---- known answers of the reference's material / frame helpers (tests/golden/ref_matkat.json) ------------------------------------------
+def _f32a(rows, key):
+    return np.array([[f32(b) for b in r[key]] for r in rows], np.float32)
+
+
+class OracleMatkat:
+    """The oracle's copies of reflect / refract / scatter_metal / scatter_dielectric / build_onb / schlick, batch interface (one row per case)."""
+
+    def __init__(self, oracle):
+        L = self.L = oracle.lib
+        F3 = C.POINTER(C.c_float)
+        L.dsrt_oracle_reflect.restype = None
+        L.dsrt_oracle_reflect.argtypes = [F3, F3, F3]
+        L.dsrt_oracle_refract.restype = None
+        L.dsrt_oracle_refract.argtypes = [F3, F3, C.c_float, F3]
+        L.dsrt_oracle_normalize.restype = None
+        L.dsrt_oracle_normalize.argtypes = [F3, F3]
+        L.dsrt_oracle_scatter_metal.restype = C.c_int
+        L.dsrt_oracle_scatter_metal.argtypes = [F3, F3, C.c_float, C.POINTER(C.c_uint32), F3]
+        L.dsrt_oracle_scatter_dielectric.restype = None
+        L.dsrt_oracle_scatter_dielectric.argtypes = [F3, F3, C.c_int, C.c_float, C.POINTER(C.c_uint32), F3]
+        L.dsrt_oracle_build_onb.restype = None
+        L.dsrt_oracle_build_onb.argtypes = [F3, F3, F3, F3]
+        L.dsrt_oracle_schlick.restype = C.c_float
+        L.dsrt_oracle_schlick.argtypes = [C.c_float, C.c_float]
+
+    @staticmethod
+    def _v(a):
+        return (C.c_float * 3)(*[float(x) for x in a])
+
+    def reflect(self, v, n):
+        out = np.zeros_like(v)
+        for i in range(len(v)):
+            o = (C.c_float * 3)()
+            self.L.dsrt_oracle_reflect(self._v(v[i]), self._v(n[i]), o)
+            out[i] = list(o)
+        return out
+
+    def refract(self, v, n, eta):
+        out = np.zeros_like(v)
+        for i in range(len(v)):
+            o = (C.c_float * 3)()
+            self.L.dsrt_oracle_refract(self._v(v[i]), self._v(n[i]), float(eta[i]), o)
+            out[i] = list(o)
+        return out
+
+    def normalize(self, v):
+        out = np.zeros_like(v)
+        for i in range(len(v)):
+            o = (C.c_float * 3)()
+            self.L.dsrt_oracle_normalize(self._v(v[i]), o)
+            out[i] = list(o)
+        return out
+
+    def metal(self, d, n, fuzz, state):
+        out, ok, st = np.zeros_like(d), np.zeros(len(d), bool), np.zeros(len(d), np.uint32)
+        for i in range(len(d)):
+            o, s = (C.c_float * 3)(), C.c_uint32(int(state[i]))
+            ok[i] = bool(self.L.dsrt_oracle_scatter_metal(self._v(d[i]), self._v(n[i]), float(fuzz[i]), C.byref(s), o))
+            out[i], st[i] = list(o), s.value
+        return out, ok, st
+
+    def dielectric(self, d, n, front, ref_idx, state):
+        out, st = np.zeros_like(d), np.zeros(len(d), np.uint32)
+        for i in range(len(d)):
+            o, s = (C.c_float * 3)(), C.c_uint32(int(state[i]))
+            self.L.dsrt_oracle_scatter_dielectric(self._v(d[i]), self._v(n[i]), int(front[i]), float(ref_idx[i]), C.byref(s), o)
+            out[i], st[i] = list(o), s.value
+        return out, st
+
+    def onb(self, n):
+        u, v, w = np.zeros_like(n), np.zeros_like(n), np.zeros_like(n)
+        for i in range(len(n)):
+            a, b, c = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+            self.L.dsrt_oracle_build_onb(self._v(n[i]), a, b, c)
+            u[i], v[i], w[i] = list(a), list(b), list(c)
+        return u, v, w
+
+    def schlick(self, cos, ratio):
+        return np.array([self.L.dsrt_oracle_schlick(float(a), float(b)) for a, b in zip(cos, ratio)], np.float32)
+
+
+def check_material_known_answers(impl, normalize):
+    """`impl` (the oracle, or the device helpers behind dsrt_selftest_devkat) against what the reference's host code computed
+    (oracle/ref_host_driver.cpp `matkat`).  Values are compared as floats (+0 == -0: the host adds `0.0f * vector` where the kernel adds
+    `vector * 0.0f`); `normalize` is the oracle's f3_norm, used to tell which refract inputs survive the kernel's extra normalisation."""
+    kat = json.load(open(os.path.join(GOLDEN, "ref_matkat.json")))
+    # reflect (inc/vec3.h:136-139 = src/gpu_render.cu:195): float arithmetic on both sides
+    rows = kat["reflect"]
+    assert np.array_equal(impl.reflect(_f32a(rows, "v"), _f32a(rows, "n")), _f32a(rows, "out"))
+    # refract (inc/vec3.h:141-147 = :199-206 after the kernel's f3_norm of its argument)
+    rows = kat["refract"]
+    uv, n, eta, want = _f32a(rows, "uv"), _f32a(rows, "n"), np.array([f32(r["eta"]) for r in rows], np.float32), _f32a(rows, "out")
+    got = impl.refract(uv, n, eta)
+    same_after_norm = (normalize(uv).view(np.uint32) == uv.view(np.uint32)).all(axis=1)
+    assert same_after_norm.sum() >= 16, same_after_norm.sum()
+    assert np.array_equal(got[same_after_norm], want[same_after_norm])
+    assert np.abs(got - want).max() <= 2e-6                                  # the others (|out| up to 2.4) differ by the re-normalisation's rounding only
+    # metal::scatter at fuzz 0 (inc/material.h:123-137 = scatter_metal :603-619): direction, accept test, and a whole number of rejection-loop trips
+    rows = kat["metal_fuzz0"]
+    state = np.array([(7919 * i + 13) & 0xFFFFFFFF for i in range(len(rows))], np.uint32)
+    out, ok, st = impl.metal(_f32a(rows, "dir"), _f32a(rows, "n"), np.zeros(len(rows), np.float32), state)
+    assert np.array_equal(out, _f32a(rows, "out"))
+    want_ok = np.array([r["ok"] for r in rows], bool)
+    assert np.array_equal(ok, want_ok) and 8 < want_ok.sum() < len(rows) - 8       # both outcomes are exercised
+    for s0, s1 in zip(state, st):
+        s, trips = int(s0), 0
+        while s != int(s1) and trips < 64:
+            for _ in range(3):
+                s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            trips += 1
+        assert 1 <= trips < 64
+    # dielectric::scatter, total internal reflection (inc/material.h:153-180 = scatter_dielectric :621-661): reflect(unit_dir, n), and NO draw
+    rows = kat["dielectric_tir"]
+    state = np.array([(104729 * i + 7) & 0xFFFFFFFF for i in range(len(rows))], np.uint32)
+    out, st = impl.dielectric(_f32a(rows, "dir"), _f32a(rows, "n"), np.array([r["front"] for r in rows], np.int32),
+                              np.array([f32(r["ref_idx"]) for r in rows], np.float32), state)
+    assert np.array_equal(out, _f32a(rows, "out"))
+    assert np.array_equal(st, state)                                          # `cannot_refract || ...` short-circuits: the stream does not move
+    assert {r["front"] for r in rows} == {0, 1}
+    # reflectance (inc/material.h:28-32, double) = schlick :208-212 (float, shared deterministic powf): to rounding
+    rows = kat["reflectance"]
+    got = impl.schlick(np.array([f32(r["cos"]) for r in rows], np.float32), np.array([f32(r["ratio"]) for r in rows], np.float32))
+    want = np.array([struct.unpack("<d", struct.pack("<Q", r["out_f64"]))[0] for r in rows])
+    assert np.abs(got.astype(np.float64) - want).max() <= 3e-7
+    # onb::build_from_w (inc/onb.h:47-56) = build_onb :112-118: same w and v; the class forms u = w x v, the kernel u = v x w = -(w x v), exactly
+    rows = kat["onb"]
+    u, v, w = impl.onb(_f32a(rows, "n"))
+    assert np.array_equal(w, _f32a(rows, "w")) and np.array_equal(v, _f32a(rows, "v")) and np.array_equal(u, -_f32a(rows, "u"))
+    assert sum(abs(f32(r["w"][0])) > 0.9 for r in rows) >= 6                  # both helper axes are exercised
+
+
+def test_material_and_frame_known_answers_from_the_reference(oracle):
+    """What ray_color's specular branches and the cosine sampler are made of, pinned by the reference's own host code, executed:
+    after this the unpinned part of the oracle is ray_color's control flow, scene_hit's combination and the traversal order -- nothing else."""
+    impl = OracleMatkat(oracle)
+    check_material_known_answers(impl, impl.normalize)

@@ -8,7 +8,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/valu_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/tools/valu_ceiling.py > $out/sweep.jsonl 2> $out/sweep.err || echo "sweep failed" >> $out/fail.log
-timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -- python3 $GRAFT_REPO_ROOT/tools/valu_ceiling.py --pmc > $out/pmc.log 2>&1 || echo "pmc pass failed" >> $out/fail.log
+timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc -- python3 $GRAFT_REPO_ROOT/tools/valu_ceiling.py --pmc > $out/pmc.log 2>&1 || echo "pmc pass failed" >> $out/fail.log
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
