@@ -69,10 +69,13 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(d, scene, W, H, spp, budget_s):
+def cpu_baseline(d, scene, W, H, spp, budget_s, gpu_rgb8=None):
     """The CPU oracle (oracle/dsrt_oracle.c, kind "port") on a bounded sample of the SAME frame: single rows at full spp, spread evenly
     over the whole image height (a stratified sample: centre rows alone would over-weight the station), one row per thread per round,
-    rounds added until the time budget is used up."""
+    rounds added until the time budget is used up.  The rows' pixels are KEPT: with `gpu_rgb8` (the H x W x 3 image of the timed GPU step,
+    on the host) they are compared byte for byte -- outside any timed region -- and the result is returned as `parity_rows`, which ties the
+    headline number to bytes the oracle agrees with on the very mesh and frame it was measured on."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
     orc = Oracle()
@@ -85,10 +88,11 @@ def cpu_baseline(d, scene, W, H, spp, budget_s):
                 seen.add(y)
                 order.append(y)
         step //= 2
+    cpu_img = np.zeros((H, W, 3), np.uint8)            # dsrt_oracle_render_rows writes kernel row y into image row H - 1 - y; threads touch disjoint rows
 
     def one_round(rows):
         cnt = [(C.c_uint64 * len(Oracle.COUNTER_NAMES))() for _ in rows]
-        jobs = [threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y, y + 1, None, None, cnt[i]))
+        jobs = [threading.Thread(target=orc.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y, y + 1, cpu_img.ctypes.data, None, cnt[i]))
                 for i, y in enumerate(rows)]
         for th in jobs:
             th.start()
@@ -105,9 +109,16 @@ def cpu_baseline(d, scene, W, H, spp, budget_s):
         if dt >= budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": rows * W * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+    base = {"value": rows * W * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{rows} full rows spread evenly over the image height (rows {sorted(order[:rows])[:3]}...), same frame at {W}x{H}x{spp} "
                       f"({rows * W} pixels), {dt:.1f} s wall"}
+    parity = None
+    if gpu_rgb8 is not None:
+        img_rows = [H - 1 - y for y in order[:rows]]
+        diff = (cpu_img[img_rows] != gpu_rgb8[img_rows]).any(axis=2)
+        parity = {"rows": rows, "pixels": int(rows * W), "mismatched": int(diff.sum()), "lit_pixels": int((cpu_img[img_rows].max(axis=2) > 0).sum()),
+                  "compared": "rgb8 bytes of the oracle's rows against the same rows of the GPU image of the last timed step (rng_mode 0)"}
+    return base, parity
 
 
 def book_baseline(obj_path, fr, cores, tsv_path=None):
@@ -549,9 +560,30 @@ def main():
             dt = float(t.item())
         return dt
 
+    def all_ranks_can(local_action, what):
+        """Runs `local_action` (no collective inside: a render that makes the library allocate this mode's buffers) on every rank and agrees on the
+        outcome BEFORE anybody enters a collective: a rank that failed alone would leave the others waiting in the gather for ever."""
+        try:
+            local_action()
+            mine_ok = 1.0
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py rank {rank}: {what}: {e}", file=sys.stderr, flush=True)
+            mine_ok = 0.0
+        if world == 1:
+            return mine_ok == 1.0
+        agreed = torch.tensor([mine_ok], dtype=torch.float64, device=dev)
+        all_reduce(agreed, dist.ReduceOp.MIN)
+        return float(agreed.item()) == 1.0
+
+    if not all_ranks_can(lambda: ctx.render(desc, part.data_ptr(), stream=stream, want_stats=True), "first render of the headline configuration"):
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit("bench.py: a rank could not render the headline configuration (see stderr); nothing was measured")
     dt = timed(args.steps, args.warmup)
     my_kernel_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     headline_stats = list(last_stats)
+    # the image of the last timed step, kept on the host for the parity check against the oracle's rows (after the timed region, before anything overwrites it)
+    headline_image = image[:W * H * 3].cpu().numpy().reshape(H, W, 3) if rank == 0 and not args.no_cpu else None
     rehearsal_report = None
     if rehearsal and rank == 0:                                     # (before the rng_mode 1 steps below overwrite `image`)
         whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
@@ -601,12 +633,56 @@ def main():
     mode1 = None
     if shard:
         step_desc[0] = d.make_desc(W, H, spp, depth, shard_rank=rank, shard_count=shard, stack_entries=args.stack_entries, rng_mode=1)
-        dt1 = timed(args.steps, 1)
-        mode1 = {"rng_mode": 1, "value": W * H * spp * args.steps / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 / args.steps * 1e3,
-                 "rank0_kernel_ms": sum(kernel_ms) / max(1, len(kernel_ms)),
-                 "note": "same frame, same tile sharding, gather and de-interleave inside the step; statistically equivalent image (DESIGN.md section 4)"}
+        # (rng_mode 1 makes the library allocate its integer-sum buffer: agree that every rank got it before the first gather of this leg)
+        if all_ranks_can(lambda: ctx.render(step_desc[0], part.data_ptr(), stream=stream, want_stats=True), "first render in rng_mode 1"):
+            dt1 = timed(args.steps, 1)
+            mode1 = {"rng_mode": 1, "value": W * H * spp * args.steps / dt1 / 1e6, "unit": "Msamples/s", "ms_per_step": dt1 / args.steps * 1e3,
+                     "rank0_kernel_ms": sum(kernel_ms) / max(1, len(kernel_ms)),
+                     "note": "same frame, same tile sharding, gather and de-interleave inside the step; statistically equivalent image (DESIGN.md section 4)"}
+        else:
+            mode1 = {"error": "a rank could not render in rng_mode 1"}
         step_desc[0] = desc
         last_stats[:] = headline_stats
+    # N > 1: what scales, in one object a reader needs no other document for.  The three ways this frame can be rendered on N GPUs (one launch per
+    # step in the reference's stream; the same with a Philox stream per sample; K frames per launch), each against ITS OWN one-GPU time, measured
+    # in this run: rank 0 renders the whole frame alone while the other ranks wait at the barrier.  Only measured figures go in here.
+    scaling_detail = None
+    if shard:
+        one_gpu = {}
+        if rank == 0:
+            whole = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
+
+            def alone(action, reps=2):
+                action()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    action()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3
+            try:
+                one_gpu["single_launch_rng_mode_0"] = alone(lambda: ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries), whole.data_ptr(), stream=stream, want_stats=True))
+                one_gpu["single_launch_rng_mode_1"] = alone(lambda: ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, rng_mode=1), whole.data_ptr(), stream=stream, want_stats=True))
+                if batched and "ms_per_frame" in batched:
+                    nb1 = batched["frames_in_the_launch"]
+                    wholes = torch.zeros(nb1 * W * H * 3, dtype=torch.uint8, device=dev)
+                    sun1 = tuple(fr.sun_dir_model)
+                    one_gpu["batch_launch_rng_mode_0"] = alone(lambda: ctx.render_batch(d.make_desc(W, H, spp, depth), [cam] * nb1, [sun1] * nb1, wholes.data_ptr(), stream=stream, want_stats=True), reps=1) / nb1
+                    del wholes
+            except Exception as e:  # noqa: BLE001 -- local work only: the other ranks are at the barrier below either way
+                one_gpu["error"] = str(e)[:200]
+            del whole
+        dist.barrier()
+        if rank == 0:
+            n_gpu = {"single_launch_rng_mode_0": dt / args.steps * 1e3,
+                     "single_launch_rng_mode_1": mode1.get("ms_per_step") if mode1 else None,
+                     "batch_launch_rng_mode_0": batched.get("ms_per_frame") if batched else None}
+            scaling_detail = {"n_gpus": n_gpus, "unit": "ms per 1920x1080x1000 frame (wall clock, gather and de-interleave included for N GPUs)" if (W, H, spp) == (1920, 1080, 1000) else "ms per frame (wall clock)",
+                              "one_gpu_ms_measured_in_this_run_on_rank_0": one_gpu, "n_gpu_ms": n_gpu,
+                              "speedup_vs_1gpu": {k: (one_gpu[k] / n_gpu[k] if one_gpu.get(k) and n_gpu.get(k) else None) for k in n_gpu},
+                              "frames_in_the_batch_launch": batched.get("frames_in_the_launch") if batched else None,
+                              "note": "single_launch_rng_mode_0 is the headline (parity mode: one LCG stream per pixel, so a pixel is a serial chain of spp samples and one frame's speed-up "
+                                      "is bound by its longest chain); rng_mode 1 (Philox stream per sample) and K frames per launch are the forms whose work units are small enough to scale"}
     tiles_total, tiles_culled = (last_stats[0].tiles_total, last_stats[0].tiles_culled) if last_stats else (0, 0)
 
     # ---- work counters of exactly this launch shape (untimed counting build), for Mrays/s and the algorithmic bytes ----
@@ -814,10 +890,12 @@ def main():
             out["rng_mode_1_same_sharding"] = mode1
         if batched:
             out["steps_as_one_sharded_batch_launch"] = batched
+        if scaling_detail:
+            out["scaling_detail"] = scaling_detail
         if rehearsal_report:
             out["rehearsal"] = rehearsal_report
         if n_gpus == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget)
+            out["cpu_baseline"], out["parity_rows"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget, gpu_rgb8=headline_image)
             if not args.no_extras:
                 out["cpu_baseline_book"] = book_baseline(obj, fr, host_cores(), os.path.join(ROOT, "gpurun_out", "timings_threads.tsv"))
         print(json.dumps(out), flush=True)

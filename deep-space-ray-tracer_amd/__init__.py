@@ -208,18 +208,21 @@ def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_
             "ms": ms.value, "records": rec.value, "Grecords_per_s": rec.value / ms.value / 1e6}
 
 
-VALU_KINDS = ("v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cmp+v_cndmask_b32(vcc)", "v_max3_f32", "v_add_f32", "v_mul_f32", "v_cndmask_b32_e64(sgpr pair)",
-              "s_mov vcc+v_cndmask_b32(vcc)", "v_cmp_lt_f32", "v_min_f32", "v_mov_b32", "v_pk_add_f32", "v_rcp_f32", "mix(fma,cnd,pk_mul,cnd,max3,pk_add,add,cnd)", "v_and_b32")
+VALU_KINDS = tuple(lib.dsrt_microbench_valu_kind_name(k).decode() for k in range(lib.dsrt_microbench_valu_kinds()))
 
 
-def microbench_valu(kind=0, waves_per_simd=4, iters=20000, lane_mask=(1 << 64) - 1, device=0):
-    """VALU issue calibration (include/dsrt.h): {"ms", "wave_instructions", "cycles_per_instruction_per_simd", ...}."""
-    ms, n, cyc, ghz = C.c_float(), C.c_double(), C.c_double(), C.c_double()
-    _check(lib.dsrt_microbench_valu(int(device), int(kind), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(cyc), C.byref(ghz)),
+def microbench_valu(kind=0, waves_per_simd=8, iters=20000, lane_mask=(1 << 64) - 1, pattern=0, device=0, simds=1024):
+    """VALU issue-cost calibration (include/dsrt.h).  `kind`: index or name (VALU_KINDS).  cycles_per_instruction_per_simd is for the stream as issued:
+    with pattern 1 or 2 half of the instructions are v_add_f32."""
+    if isinstance(kind, str):
+        kind = VALU_KINDS.index(kind)
+    ms, n, ghz = C.c_float(), C.c_double(), C.c_double()
+    _check(lib.dsrt_microbench_valu(int(device), int(kind), int(pattern), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(ghz)),
            "dsrt_microbench_valu")
-    return {"kind": VALU_KINDS[kind], "waves_per_simd": waves_per_simd, "iters": iters,
-            "lanes": bin(lane_mask).count("1"), "lane_mask": hex(lane_mask), "ms": ms.value, "wave_instructions": n.value,
-            "G_wave_instructions_per_s": n.value / ms.value / 1e6, "memtime_ticks_per_instruction_per_simd": cyc.value, "memtime_GHz": ghz.value}
+    gips = n.value / ms.value / 1e6
+    return {"kind": VALU_KINDS[kind], "pattern": ("x32", "alternating with v_add_f32", "pairs between pairs of v_add_f32")[pattern], "waves_per_simd": waves_per_simd, "iters": iters,
+            "lanes": bin(lane_mask).count("1"), "ms": ms.value, "wave_instructions": n.value, "G_wave_instructions_per_s": gips, "shader_clock_GHz": ghz.value,
+            "cycles_per_instruction_per_simd": simds * ghz.value / gips}
 
 
 def stats_dict(st):

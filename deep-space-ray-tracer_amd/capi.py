@@ -109,7 +109,7 @@ EXPORTS = [
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
     "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_selftest_rccl_gather", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
     "dsrt_scene_set_camera_sun", "dsrt_shard_layout", "dsrt_ctx_scene_bounds", "dsrt_render", "dsrt_render_batch", "dsrt_render_batch_to_host", "dsrt_deinterleave_tiles", "dsrt_deinterleave_batch", "dsrt_render_to_host",
-    "dsrt_selftest_math", "dsrt_selftest_devkat", "dsrt_selftest_philox", "dsrt_microbench_gather", "dsrt_microbench_valu", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
+    "dsrt_selftest_math", "dsrt_selftest_devkat", "dsrt_selftest_philox", "dsrt_microbench_gather", "dsrt_microbench_valu", "dsrt_microbench_valu_kinds", "dsrt_microbench_valu_kind_name", "gpu_render_scene", "dsrt_build_gpu_scene", "dsrt_free_gpu_scene",
 ]
 
 
@@ -185,7 +185,9 @@ def load():
     sig("dsrt_selftest_devkat", C.c_int, [vp, C.c_int, vp, vp, C.c_int])
     sig("dsrt_selftest_philox", C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp, vp])
     sig("dsrt_microbench_gather", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, P(C.c_float), P(C.c_double)])
-    sig("dsrt_microbench_valu", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P(C.c_float), P(C.c_double), P(C.c_double), P(C.c_double)])
+    sig("dsrt_microbench_valu", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, P(C.c_float), P(C.c_double), P(C.c_double)])
+    sig("dsrt_microbench_valu_kinds", C.c_int, [])
+    sig("dsrt_microbench_valu_kind_name", C.c_char_p, [C.c_int])
     sig("gpu_render_scene", None, [P(GPUScene), C.c_int, C.c_int])
     sig("dsrt_build_gpu_scene", C.c_int, [vp, P(GPUCamera), P(C.c_float), P(GPUScene)])
     sig("dsrt_free_gpu_scene", None, [P(GPUScene)])

@@ -131,6 +131,7 @@ struct RenderArgs {
     int       helpers;         // 1: idle lanes trace shadow rays for busy lanes of their wave (path_machine.h)
     int       steal;           // rng_mode 1: 1 = a lane that is out of work takes over half the remaining samples of a busy lane of its wave
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
+    int       deal_leaves;     // 1: a parked leaf's second pair record is evaluated by a lane that is not at a leaf (render_kernel.hip, phase L)
 };
 
 // order matches the DsrtStats tail in include/dsrt.h

@@ -107,29 +107,52 @@ gather_kernel(const float4* __restrict__ table, uint32_t n_rec, int iters, int l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The vector-ALU ISSUE ceiling (dsrt_microbench_valu).  The render kernel is bound by VALU issue, so the ceiling it is priced against
-// has to be measured, not assumed: `waves_per_simd` waves on every SIMD of the chip each run `iters` x 32 instructions of ONE kind
-// from EIGHT INDEPENDENT register streams (no instruction reads the result of any of the seven before it), written as inline
-// assembly so that the instruction counted is the instruction issued.  The launch carries enough dynamic LDS per workgroup that
-// exactly `waves_per_simd` workgroups fit a CU, so the grid of CUs x waves_per_simd workgroups is spread evenly whatever the
-// dispatcher's order.  Every wave stamps its loop with the shader-clock counter (s_memtime) and the 100 MHz wall clock
-// (s_memrealtime); the host reports instructions per second, cycles per wave-instruction per SIMD by those stamps, and the
-// frequency the s_memtime counter ran at.  The PMC route (SQ_INSTS_VALU over GRBM_GUI_ACTIVE) is tools/valu_pmc.sh.
-//   kind  0 v_fma_f32          1 v_pk_fma_f32            2 v_pk_mul_f32        3 v_cmp + 32 x v_cndmask_b32 (vcc)    4 v_max3_f32
-//         5 v_add_f32          6 v_mul_f32               7 v_cndmask_b32_e64 (mask in an SGPR pair)
-//         8 v_cndmask_b32 (vcc set by s_mov)             9 v_cmp_lt_f32 vcc   10 v_min_f32         11 v_mov_b32      12 v_pk_add_f32
-//        13 v_rcp_f32         14 a mix: fma, cndmask, pk_mul, cndmask, max3, pk_add, add, cndmask                    15 v_and_b32
+// The vector-ALU ISSUE cost of every instruction kind the render kernel is made of (dsrt_microbench_valu).  The render kernel is
+// bound by VALU issue, so the ceiling it is priced against has to be measured, not assumed: `waves_per_simd` workgroups per CU (one
+// wave per SIMD each; enough dynamic LDS per workgroup that no more fit) each run `iters` x 32 instructions from EIGHT INDEPENDENT
+// register streams (no instruction reads the result of any of the seven before it), written as inline assembly so that the instruction
+// counted is the instruction issued.  pattern 0: 32 x the instruction; pattern 1: 16 x (the instruction, then a v_add_f32 on another
+// stream) -- some kinds cost far more back to back than next to something else; pattern 2: 8 x (the instruction twice, v_add_f32 twice).
+// Every wave stamps its loop with the shader-clock counter (s_memtime) and the 100 MHz wall clock (s_memrealtime); the host reports
+// instructions per second and the frequency the shader clock ran at, i.e. cycles per wave-instruction per SIMD.  The PMC route
+// (SQ_INSTS_VALU over GRBM_GUI_ACTIVE) is tools/valu_pmc.sh.  Kinds: kValuKindNames below.
 // `lane_mask`: the lanes of every wave that execute the loop (the rest branch around it): does a half-empty wave issue faster?
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v2f_mb __attribute__((ext_vector_type(2)));
-constexpr int kValuKinds = 16;
+constexpr int kValuKinds = 32;
+const char* const kValuKindNames[kValuKinds] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_cndmask_b32_e32(vcc)", "v_max3_f32", "v_add_f32", "v_mul_f32", "v_cndmask_b32_e64(sgpr pair)", "v_cndmask_b32_e64(vcc)", "v_cmp_lt_f32_e32(vcc)", "v_min_f32", "v_mov_b32", "v_pk_add_f32", "v_rcp_f32", "v_cmp_lt_f32_e64(sgpr pair)", "v_and_b32", "v_bfi_b32", "v_max_f32", "v_med3_f32", "v_sub_f32", "v_add_u32", "v_lshlrev_b32", "v_mul_lo_u32", "v_fmac_f32", "v_xor_b32", "v_cvt_f32_u32", "v_sqrt_f32", "v_min3_f32", "v_pk_mov_b32", "v_mov_b32_dpp(quad_perm)", "v_lshl_add_u32", "v_or_b32"};
 
+#define DSRT_A0 "%0"
+#define DSRT_A1 "%1"
+#define DSRT_A2 "%2"
+#define DSRT_A3 "%3"
+#define DSRT_A4 "%4"
+#define DSRT_A5 "%5"
+#define DSRT_A6 "%6"
+#define DSRT_A7 "%7"
+#define DSRT_P0 "%8"
+#define DSRT_P1 "%9"
+#define DSRT_P2 "%10"
+#define DSRT_P3 "%11"
+#define DSRT_P4 "%12"
+#define DSRT_P5 "%13"
+#define DSRT_P6 "%14"
+#define DSRT_P7 "%15"
+#define A(i) DSRT_A##i
+#define P(i) DSRT_P##i
+#define DSRT_ADD(i) "v_add_f32 " A(i) ", " A(i) ", %17\n\t"
 #define DSRT_R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
-#define DSRT_R32(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP)
-#define DSRT_SCALAR_ASM(PRE, OP) asm volatile(PRE DSRT_R32(OP) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c), "s"(smask) : "vcc")
-#define DSRT_PAIR_ASM(OP) asm volatile(DSRT_R32(OP) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc))
+#define DSRT_PAT0(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(OP)
+#define DSRT_PAT1(OP) OP(0) DSRT_ADD(4) OP(1) DSRT_ADD(5) OP(2) DSRT_ADD(6) OP(3) DSRT_ADD(7) OP(0) DSRT_ADD(4) OP(1) DSRT_ADD(5) OP(2) DSRT_ADD(6) OP(3) DSRT_ADD(7) \
+                      OP(0) DSRT_ADD(4) OP(1) DSRT_ADD(5) OP(2) DSRT_ADD(6) OP(3) DSRT_ADD(7) OP(0) DSRT_ADD(4) OP(1) DSRT_ADD(5) OP(2) DSRT_ADD(6) OP(3) DSRT_ADD(7)
+#define DSRT_PAT2(OP) OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7) OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7) \
+                      OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7) OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7)
+#define DSRT_VALU_OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) \
+                           : "v"(m), "v"(c), "v"(pm), "v"(pc), "s"(smask) : "vcc", "s20", "s21"
+#define DSRT_VALU_ASM(OP) do { if (PATTERN == 0) asm volatile(DSRT_PAT0(OP) DSRT_VALU_OPERANDS); else if (PATTERN == 1) asm volatile(DSRT_PAT1(OP) DSRT_VALU_OPERANDS); \
+                               else asm volatile(DSRT_PAT2(OP) DSRT_VALU_OPERANDS); } while (0)
 
-template <int KIND>
+template <int KIND, int PATTERN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
 valu_kernel(int iters, unsigned long long lane_mask, unsigned long long smask, unsigned long long* __restrict__ stamps, float* __restrict__ sink) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -143,72 +166,166 @@ valu_kernel(int iters, unsigned long long lane_mask, unsigned long long smask, u
     if ((lane_mask >> lane) & 1ull) {
         r0 = __builtin_amdgcn_s_memrealtime();
         t0 = __builtin_readcyclecounter();
+        asm volatile("s_mov_b64 vcc, %0" :: "s"(smask) : "vcc");       // the selects on vcc read this (nothing else in the loop writes vcc, except the compare kind)
         for (int it = 0; it < iters; ++it) {
             if (KIND == 0) {
-#define DSRT_OP(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+#define DSRT_OP(i) "v_fma_f32 " A(i) ", " A(i) ", %16, %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 1) {
-#define DSRT_OP(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n\t"
-                DSRT_PAIR_ASM(DSRT_OP);
+            }
+            else if (KIND == 1) {
+#define DSRT_OP(i) "v_pk_fma_f32 " P(i) ", " P(i) ", %18, %19\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 2) {
-#define DSRT_OP(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n\t"
-                DSRT_PAIR_ASM(DSRT_OP);
+            }
+            else if (KIND == 2) {
+#define DSRT_OP(i) "v_pk_mul_f32 " P(i) ", " P(i) ", %18\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 3) {
-#define DSRT_OP(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
-                DSRT_SCALAR_ASM("v_cmp_gt_f32 vcc, %8, %9\n\t", DSRT_OP);
+            }
+            else if (KIND == 3) {
+#define DSRT_OP(i) "v_cndmask_b32_e32 " A(i) ", " A(i) ", %16, vcc\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 4) {
-#define DSRT_OP(i) "v_max3_f32 %" #i ", %" #i ", %8, %9\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 4) {
+#define DSRT_OP(i) "v_max3_f32 " A(i) ", " A(i) ", %16, %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 5) {
-#define DSRT_OP(i) "v_add_f32 %" #i ", %" #i ", %9\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 5) {
+#define DSRT_OP(i) "v_add_f32 " A(i) ", " A(i) ", %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 6) {
-#define DSRT_OP(i) "v_mul_f32 %" #i ", %" #i ", %8\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 6) {
+#define DSRT_OP(i) "v_mul_f32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 7) {
-#define DSRT_OP(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, %10\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 7) {
+#define DSRT_OP(i) "v_cndmask_b32_e64 " A(i) ", " A(i) ", %16, %20\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 8) {
-#define DSRT_OP(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
-                DSRT_SCALAR_ASM("s_mov_b64 vcc, %10\n\t", DSRT_OP);
+            }
+            else if (KIND == 8) {
+#define DSRT_OP(i) "v_cndmask_b32_e64 " A(i) ", " A(i) ", %16, vcc\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 9) {
-#define DSRT_OP(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 9) {
+#define DSRT_OP(i) "v_cmp_lt_f32_e32 vcc, " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 10) {
-#define DSRT_OP(i) "v_min_f32 %" #i ", %" #i ", %8\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 10) {
+#define DSRT_OP(i) "v_min_f32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 11) {
-#define DSRT_OP(i) "v_mov_b32 %" #i ", %8\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 11) {
+#define DSRT_OP(i) "v_mov_b32 " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 12) {
-#define DSRT_OP(i) "v_pk_add_f32 %" #i ", %" #i ", %9\n\t"
-                DSRT_PAIR_ASM(DSRT_OP);
+            }
+            else if (KIND == 12) {
+#define DSRT_OP(i) "v_pk_add_f32 " P(i) ", " P(i) ", %19\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 13) {
-#define DSRT_OP(i) "v_rcp_f32 %" #i ", %" #i "\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 13) {
+#define DSRT_OP(i) "v_rcp_f32 " A(i) ", " A(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
-            } else if (KIND == 14) {
-#define DSRT_MIX "v_fma_f32 %0, %0, %8, %9\n\tv_cndmask_b32_e64 %1, %1, %8, %12\n\tv_pk_mul_f32 %4, %4, %10\n\tv_cndmask_b32_e64 %2, %2, %8, %12\n\t" \
-                 "v_max3_f32 %3, %3, %8, %9\n\tv_pk_add_f32 %5, %5, %11\n\tv_add_f32 %0, %0, %9\n\tv_cndmask_b32_e64 %1, %1, %9, %12\n\t"
-                asm volatile(DSRT_MIX DSRT_MIX DSRT_MIX DSRT_MIX
-                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(m), "v"(c), "v"(pm), "v"(pc), "s"(smask));
-#undef DSRT_MIX
-            } else {
-#define DSRT_OP(i) "v_and_b32 %" #i ", %" #i ", %8\n\t"
-                DSRT_SCALAR_ASM("", DSRT_OP);
+            }
+            else if (KIND == 14) {
+#define DSRT_OP(i) "v_cmp_lt_f32_e64 s[20:21], " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 15) {
+#define DSRT_OP(i) "v_and_b32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 16) {
+#define DSRT_OP(i) "v_bfi_b32 " A(i) ", %16, %17, " A(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 17) {
+#define DSRT_OP(i) "v_max_f32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 18) {
+#define DSRT_OP(i) "v_med3_f32 " A(i) ", " A(i) ", %16, %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 19) {
+#define DSRT_OP(i) "v_sub_f32 " A(i) ", " A(i) ", %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 20) {
+#define DSRT_OP(i) "v_add_u32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 21) {
+#define DSRT_OP(i) "v_lshlrev_b32 " A(i) ", 1, " A(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 22) {
+#define DSRT_OP(i) "v_mul_lo_u32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 23) {
+#define DSRT_OP(i) "v_fmac_f32 " A(i) ", %16, %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 24) {
+#define DSRT_OP(i) "v_xor_b32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 25) {
+#define DSRT_OP(i) "v_cvt_f32_u32 " A(i) ", " A(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 26) {
+#define DSRT_OP(i) "v_sqrt_f32 " A(i) ", " A(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 27) {
+#define DSRT_OP(i) "v_min3_f32 " A(i) ", " A(i) ", %16, %17\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 28) {
+#define DSRT_OP(i) "v_pk_mov_b32 " P(i) ", %18, " P(i) "\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 29) {
+#define DSRT_OP(i) "v_mov_b32_dpp " A(i) ", " A(i) " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 30) {
+#define DSRT_OP(i) "v_lshl_add_u32 " A(i) ", " A(i) ", 1, %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
+#undef DSRT_OP
+            }
+            else if (KIND == 31) {
+#define DSRT_OP(i) "v_or_b32 " A(i) ", " A(i) ", %16\n\t"
+                DSRT_VALU_ASM(DSRT_OP);
 #undef DSRT_OP
             }
         }
@@ -220,16 +337,25 @@ valu_kernel(int iters, unsigned long long lane_mask, unsigned long long smask, u
     const float r = (((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7))) + (((p0.x + p1.y) + (p2.x + p3.y)) + ((p4.x + p5.y) + (p6.x + p7.y)));
     if (r == 123.456f) sink[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
+#undef A
+#undef P
+
+template <int KIND, int PATTERN>
+hipError_t launch_valu_one(int blocks, size_t lds, int iters, unsigned long long lane_mask, unsigned long long* stamps, float* sink) {
+    hipError_t e = hipFuncSetAttribute((const void*)valu_kernel<KIND, PATTERN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((valu_kernel<KIND, PATTERN>), dim3(blocks), dim3(256), lds, nullptr, iters, lane_mask, 0x5A5A5A5AA5A5A5A5ull, stamps, sink);
+    return hipGetLastError();
+}
 
 template <int KIND>
-hipError_t launch_valu(int kind, int blocks, size_t lds, int iters, unsigned long long lane_mask, unsigned long long* stamps, float* sink) {
+hipError_t launch_valu(int kind, int pattern, int blocks, size_t lds, int iters, unsigned long long lane_mask, unsigned long long* stamps, float* sink) {
     if (kind == KIND) {
-        hipError_t e = hipFuncSetAttribute((const void*)valu_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(valu_kernel<KIND>, dim3(blocks), dim3(256), lds, nullptr, iters, lane_mask, 0x5A5A5A5AA5A5A5A5ull, stamps, sink);
-        return hipGetLastError();
+        if (pattern == 0) return launch_valu_one<KIND, 0>(blocks, lds, iters, lane_mask, stamps, sink);
+        if (pattern == 1) return launch_valu_one<KIND, 1>(blocks, lds, iters, lane_mask, stamps, sink);
+        return launch_valu_one<KIND, 2>(blocks, lds, iters, lane_mask, stamps, sink);
     }
-    if constexpr (KIND + 1 < kValuKinds) return launch_valu<KIND + 1>(kind, blocks, lds, iters, lane_mask, stamps, sink);
+    if constexpr (KIND + 1 < kValuKinds) return launch_valu<KIND + 1>(kind, pattern, blocks, lds, iters, lane_mask, stamps, sink);
     return hipErrorInvalidValue;
 }
 
@@ -305,10 +431,13 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
     return DSRT_OK;
 }
 
-extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
-                                    double* out_cycles_per_instruction_per_simd, double* out_counter_GHz) {
-    if (kind < 0 || kind >= kValuKinds || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms || !out_wave_instructions ||
-        !out_cycles_per_instruction_per_simd || !out_counter_GHz) {
+extern "C" int dsrt_microbench_valu_kinds(void) { return kValuKinds; }
+extern "C" const char* dsrt_microbench_valu_kind_name(int kind) { return kind >= 0 && kind < kValuKinds ? kValuKindNames[kind] : ""; }
+
+extern "C" int dsrt_microbench_valu(int device, int kind, int pattern, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
+                                    double* out_shader_clock_GHz) {
+    if (kind < 0 || kind >= kValuKinds || pattern < 0 || pattern > 2 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms ||
+        !out_wave_instructions || !out_shader_clock_GHz) {
         dsrt::set_error("dsrt_microbench_valu: bad argument");
         return DSRT_ERR_INVALID;
     }
@@ -332,10 +461,10 @@ extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, in
     MB_TRY(hipMalloc((void**)&sink, waves * 64 * sizeof(float)));
     MB_TRY(hipEventCreate(&e0));
     MB_TRY(hipEventCreate(&e1));
-    MB_TRY(launch_valu<0>(kind, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));      // warms the clocks as well: same length as the timed run
+    MB_TRY(launch_valu<0>(kind, pattern, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));      // warms the clocks as well: same length as the timed run
     MB_TRY(hipDeviceSynchronize());
     MB_TRY(hipEventRecord(e0, nullptr));
-    MB_TRY(launch_valu<0>(kind, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));
+    MB_TRY(launch_valu<0>(kind, pattern, blocks, lds, iters, (unsigned long long)lane_mask, stamps, sink));
     MB_TRY(hipEventRecord(e1, nullptr));
     MB_TRY(hipEventSynchronize(e1));
     MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
@@ -343,10 +472,8 @@ extern "C" int dsrt_microbench_valu(int device, int kind, int waves_per_simd, in
     MB_TRY(hipMemcpy(host.data(), stamps, 2 * waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double cyc = 0, real = 0;
     for (size_t w = 0; w < waves; ++w) { cyc += (double)host[2 * w]; real += (double)host[2 * w + 1]; }
-    const double per_wave = (double)iters * (kind == 3 || kind == 8 ? 33.0 : 32.0);
-    *out_wave_instructions = per_wave * (double)waves;
-    *out_cycles_per_instruction_per_simd = (cyc / (double)waves) / ((double)waves_per_simd * per_wave);
-    *out_counter_GHz = real > 0 ? cyc / real * 0.1 : 0.0;                  // s_memrealtime ticks at 100 MHz
+    *out_wave_instructions = (double)iters * 32.0 * (double)waves;
+    *out_shader_clock_GHz = real > 0 ? cyc / real * 0.1 : 0.0;             // s_memrealtime ticks at 100 MHz
     cleanup();
     return DSRT_OK;
 }

@@ -38,6 +38,48 @@ constexpr int kWavesPerBlock = 4;
 #define DSRT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
+// Moller-Trumbore :336-353 on one pair record (two triangles, packed fp32), evaluated in full; the reference's early returns become one
+// predicate per triangle.  Each `if (x) return false` is kept as `!(x)` so that NaNs fall the same way.  The test against `closest`
+// (:353) is NOT part of this: it is applied, in order, by apply_pair.
+__device__ __forceinline__ void moller_trumbore_pair(const float4* __restrict__ tp, F3 ro, F3 rd, v2f& t, v2f& u, v2f& v, bool& ok_a, bool& ok_b) {
+    const float4 f0 = tp[0], f1 = tp[1], f2 = tp[2], f3 = tp[3];
+    const float2 f4 = *reinterpret_cast<const float2*>(tp + 4);
+    const v2f v0x = {f0.x, f0.y}, v0y = {f0.z, f0.w}, v0z = {f1.x, f1.y};
+    const v2f e1x = {f1.z, f1.w}, e1y = {f2.x, f2.y}, e1z = {f2.z, f2.w};
+    const v2f e2x = {f3.x, f3.y}, e2y = {f3.z, f3.w}, e2z = {f4.x, f4.y};
+    const v2f pvx = rd.y * e2z - rd.z * e2y, pvy = rd.z * e2x - rd.x * e2z, pvz = rd.x * e2y - rd.y * e2x;   // cross(rd, e2)
+    const v2f det = (e1x * pvx + e1y * pvy) + e1z * pvz;
+    const v2f inv_det = {1.0f / det.x, 1.0f / det.y};
+    const v2f tvx = ro.x - v0x, tvy = ro.y - v0y, tvz = ro.z - v0z;
+    u = ((tvx * pvx + tvy * pvy) + tvz * pvz) * inv_det;
+    const v2f qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;          // cross(tvec, e1)
+    v = ((rd.x * qvx + rd.y * qvy) + rd.z * qvz) * inv_det;
+    t = ((e2x * qvx + e2y * qvy) + e2z * qvz) * inv_det;
+    const v2f uv = u + v;
+    ok_a = !(fabsf(det.x) < 1e-8f) && !(u.x < 0.0f) && !(u.x > 1.0f) && !(v.x < 0.0f) && !(uv.x > 1.0f) && !(t.x < kTMin);
+    ok_b = !(fabsf(det.y) < 1e-8f) && !(u.y < 0.0f) && !(u.y > 1.0f) && !(v.y < 0.0f) && !(uv.y > 1.0f) && !(t.y < kTMin);
+}
+
+// The accepts of one pair record in the reference's order (:353, :371-379): A, then B against the `closest` A may have just lowered.
+// `slot_a` = slot of triangle A.  Returns true when the walk is over (an any-hit shadow ray found its blocker).
+template <bool COUNT, bool ANYHIT>
+__device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2f t, v2f u, v2f v, bool ok_a, bool ok_b, bool has_b) {
+    bool stop = false;
+    if (COUNT) c[C_TRI_TESTS]++;
+    if (ok_a && !(t.x > ln.closest)) {
+        ln.closest = t.x; ln.hit_slot = slot_a; ln.hit_u = u.x; ln.hit_v = v.x;
+        if (COUNT) c[C_HIT_UPDATES]++;
+        stop = ANYHIT && ln.state == ST_TRAV_SHADOW;
+    }
+    if (COUNT && has_b && !stop) c[C_TRI_TESTS]++;
+    if (!stop && ok_b && !(t.y > ln.closest)) {          // an absent B is all zeros: det == 0, never ok
+        ln.closest = t.y; ln.hit_slot = slot_a + 1; ln.hit_u = u.y; ln.hit_v = v.y;
+        if (COUNT) c[C_HIT_UPDATES]++;
+        stop = ANYHIT && ln.state == ST_TRAV_SHADOW;
+    }
+    return stop;
+}
+
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
@@ -51,8 +93,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
     Lane ln;
     ln.pend = &lds_pend[0][threadIdx.x];
     ln.aux = (uint32_t)lane;
-    int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp; int& hit_slot = ln.hit_slot;
-    float& closest = ln.closest; float& hit_u = ln.hit_u; float& hit_v = ln.hit_v; uint32_t& steps = ln.steps;
+    int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp;
+    float& closest = ln.closest; uint32_t& steps = ln.steps;
     F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
     uint32_t c[kNumCounters];
 #pragma unroll
@@ -187,7 +229,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 
             // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
             const bool at_leaf = cur < 0;
-            if (wave_any(at_leaf)) {
+            const unsigned long long leaf_mask = wave_ballot(at_leaf);
+            if (leaf_mask != 0ull) {
                 wait_waste += n_wait;
                 int first = 0, count = 0;
                 if (at_leaf) {
@@ -202,46 +245,70 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                     cur = kRefPop;
                 }
                 // Two triangles (one pair record) per step.  Every quantity is an (A, B) pair in adjacent registers; both
-                // tests are evaluated in full against the same `closest`, then applied in the reference's order: A first, and
+                // tests are evaluated in full against nothing but the ray, then APPLIED in the reference's order: A first, and
                 // B against the `closest` A may have just lowered -- the reference's sequence of accepts, bit for bit.
-                for (int i = 0; wave_any(i < count); i += 2) {
+                //
+                // Second records are DEALT to the lanes that are not at a leaf.  The median-split builder stops at four triangles, so
+                // nearly every leaf of a large mesh is two pair records, while at most a third of the wave is parked when this pass
+                // runs: the loop used to run twice at a quarter of its lanes.  Evaluating a record needs the ray and the record, not
+                // `closest`; only the accepts are ordered.  So the r-th lane that is not at a leaf evaluates record 1 of the r-th
+                // parked lane that has one (the ray comes over by ds_bpermute; its own registers are untouched), hands (t, u, v, ok)
+                // of both triangles back the same way, and the owner applies A, B of record 0 and then A, B of record 1 -- the
+                // reference's order.  Taken only when EVERY second record finds a lane (otherwise the second trip is paid anyway).
+                // Leaves of more than four triangles (coincident centroids) finish in the plain loop below.
+                int done = 0;                                              // triangles of this lane's leaf dealt with so far
+                if (args.deal_leaves) {
+                    const bool want = count > 2;
+                    const unsigned long long want_mask = wave_ballot(want);
+                    const int n_want = __popcll(want_mask);
+                    if (n_want > 0 && n_want <= 64 - __popcll(leaf_mask)) {
+                        const uint32_t rank_w = __builtin_amdgcn_mbcnt_hi((uint32_t)(want_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_mask, 0u));
+                        const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi((uint32_t)(~leaf_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~leaf_mask, 0u));
+                        float* const table = ln.pend + 13 * kPendStride - lane;          // the wave's 64-entry table (free outside advance_step)
+                        const bool helping = !at_leaf && rank_i < (uint32_t)n_want;
+                        if (want) table[rank_w] = __int_as_float(lane);
+                        lane_handoff_release();
+                        int src = lane;                                      // whose ray this lane evaluates: its own, or its owner's
+                        if (helping) { lane_handoff_acquire(); src = __float_as_int(table[rank_i]); table[rank_i] = __int_as_float(lane); }
+                        lane_handoff_release();
+                        const int src4 = src << 2;
+                        const F3 lro = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(ro.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(ro.y))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(ro.z))));
+                        const F3 lrd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.y))),
+                                          __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.z))));
+                        const int lpair = __builtin_amdgcn_ds_bpermute(src4, first) + (helping ? 1 : 0);
+                        v2f t = {0.0f, 0.0f}, u = {0.0f, 0.0f}, v = {0.0f, 0.0f};
+                        int ok = 0;                                          // bit 0: A passed every test but the one against `closest`, bit 1: B
+                        if (COUNT) c[C_TRI_SLOTS] += 2;
+                        if ((at_leaf && count > 0) || helping) {
+                            bool ok_a, ok_b;
+                            moller_trumbore_pair(S.tri_pairs + (size_t)lpair * 5, lro, lrd, t, u, v, ok_a, ok_b);
+                            ok = (ok_a ? 1 : 0) | (ok_b ? 2 : 0);
+                        }
+                        // the owner fetches its helper's results (a lane without one reads its own and ignores them)
+                        int from = lane;
+                        if (want) { lane_handoff_acquire(); from = __float_as_int(table[rank_w]); }
+                        const int from4 = from << 2;
+                        const v2f t2 = {__int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(t.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(t.y)))};
+                        const v2f u2 = {__int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(u.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(u.y)))};
+                        const v2f v2 = {__int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(v.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(v.y)))};
+                        const int ok2 = __builtin_amdgcn_ds_bpermute(from4, ok);
+                        if (at_leaf && count > 0) {
+                            bool stop = apply_pair<COUNT, ANYHIT>(ln, c, first * 2, t, u, v, (ok & 1) != 0, (ok & 2) != 0, count > 1);
+                            if (!stop && want) stop = apply_pair<COUNT, ANYHIT>(ln, c, first * 2 + 2, t2, u2, v2, (ok2 & 1) != 0, (ok2 & 2) != 0, count > 3);
+                            done = want ? 4 : 2;
+                            if (stop) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
+                        }
+                    }
+                }
+                for (int i = done; wave_any(i < count); i += 2) {
                     if (COUNT) c[C_TRI_SLOTS] += 2;
                     if (i < count) {
                         const int pair = first + (i >> 1);
-                        const float4* tp = S.tri_pairs + (size_t)pair * 5;
-                        const float4 f0 = tp[0], f1 = tp[1], f2 = tp[2], f3 = tp[3];
-                        const float2 f4 = *reinterpret_cast<const float2*>(tp + 4);
-                        const bool has_b = i + 1 < count;
-                        if (COUNT) c[C_TRI_TESTS]++;
-                        const v2f v0x = {f0.x, f0.y}, v0y = {f0.z, f0.w}, v0z = {f1.x, f1.y};
-                        const v2f e1x = {f1.z, f1.w}, e1y = {f2.x, f2.y}, e1z = {f2.z, f2.w};
-                        const v2f e2x = {f3.x, f3.y}, e2y = {f3.z, f3.w}, e2z = {f4.x, f4.y};
-                        // Moller-Trumbore :336-353, evaluated in full; the reference's early returns become one predicate.
-                        // Each `if (x) return false` is kept as `!(x)` so that NaNs fall the same way.
-                        const v2f pvx = rd.y * e2z - rd.z * e2y, pvy = rd.z * e2x - rd.x * e2z, pvz = rd.x * e2y - rd.y * e2x;   // cross(rd, e2)
-                        const v2f det = (e1x * pvx + e1y * pvy) + e1z * pvz;
-                        const v2f inv_det = {1.0f / det.x, 1.0f / det.y};
-                        const v2f tvx = ro.x - v0x, tvy = ro.y - v0y, tvz = ro.z - v0z;
-                        const v2f u = ((tvx * pvx + tvy * pvy) + tvz * pvz) * inv_det;
-                        const v2f qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;          // cross(tvec, e1)
-                        const v2f v = ((rd.x * qvx + rd.y * qvy) + rd.z * qvz) * inv_det;
-                        const v2f t = ((e2x * qvx + e2y * qvy) + e2z * qvz) * inv_det;
-                        const v2f uv = u + v;
-                        const bool ok_a = !(fabsf(det.x) < 1e-8f) && !(u.x < 0.0f) && !(u.x > 1.0f) && !(v.x < 0.0f) && !(uv.x > 1.0f) && !(t.x < kTMin);
-                        const bool ok_b = !(fabsf(det.y) < 1e-8f) && !(u.y < 0.0f) && !(u.y > 1.0f) && !(v.y < 0.0f) && !(uv.y > 1.0f) && !(t.y < kTMin);
-                        bool stop = false;
-                        if (ok_a && !(t.x > closest)) {
-                            closest = t.x; hit_slot = pair * 2; hit_u = u.x; hit_v = v.x;
-                            if (COUNT) c[C_HIT_UPDATES]++;
-                            stop = ANYHIT && state == ST_TRAV_SHADOW;
-                        }
-                        if (COUNT && has_b && !stop) c[C_TRI_TESTS]++;
-                        if (!stop && ok_b && !(t.y > closest)) {          // an absent B is all zeros: det == 0, never ok
-                            closest = t.y; hit_slot = pair * 2 + 1; hit_u = u.y; hit_v = v.y;
-                            if (COUNT) c[C_HIT_UPDATES]++;
-                            stop = ANYHIT && state == ST_TRAV_SHADOW;
-                        }
-                        if (stop) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
+                        v2f t, u, v;
+                        bool ok_a, ok_b;
+                        moller_trumbore_pair(S.tri_pairs + (size_t)pair * 5, ro, rd, t, u, v, ok_a, ok_b);
+                        if (apply_pair<COUNT, ANYHIT>(ln, c, pair * 2, t, u, v, ok_a, ok_b, i + 1 < count)) { count = 0; cur = kRefNone; state = ST_SHADOW_DONE; }
                     }
                 }
             }

@@ -330,13 +330,16 @@ int  dsrt_multi_render_sequence(DsrtMulti* m, const DsrtRenderDesc* desc, const 
 int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, int pad_valu, size_t table_bytes, int iters,
                            float* out_ms, double* out_records);
 
-/* The other calibration: the vector-ALU issue ceiling.  `waves_per_simd` (1..8) waves on every SIMD of the chip each issue iters x 32
- * instructions of one kind from eight independent register streams (kinds 0..15: v_fma_f32, v_pk_fma_f32, v_pk_mul_f32, v_cndmask_b32, ... and a
- * mix; the list is at valu_kernel in csrc/microbench.hip); only the lanes in `lane_mask` execute them.  Returns the kernel time (HIP events),
- * the wave-instructions issued, and from the waves' own stamps the s_memtime ticks per wave-instruction per SIMD and the frequency that
- * counter ran at (against the 100 MHz s_memrealtime).  No reference interface: measurement only. */
-int dsrt_microbench_valu(int device, int kind, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
-                         double* out_cycles_per_instruction_per_simd, double* out_counter_GHz);
+/* The other calibration: what a vector-ALU instruction costs to issue.  `waves_per_simd` (1..8) workgroups per CU (one wave per SIMD each) each
+ * issue iters x 32 instructions from eight independent register streams: pattern 0 = the instruction of `kind` 32 times, 1 = alternating with
+ * v_add_f32, 2 = in pairs between pairs of v_add_f32 (some kinds cost far more back to back); only the lanes in `lane_mask` execute them.
+ * Returns the kernel time (HIP events), the wave-instructions issued and the shader clock during the run (the waves' s_memtime against the
+ * 100 MHz s_memrealtime): cycles per instruction per SIMD = SIMDs x clock x time / instructions.  dsrt_microbench_valu_kinds /
+ * _kind_name enumerate the kinds.  No reference interface: measurement only. */
+int dsrt_microbench_valu(int device, int kind, int pattern, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
+                         double* out_shader_clock_GHz);
+int dsrt_microbench_valu_kinds(void);
+const char* dsrt_microbench_valu_kind_name(int kind);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

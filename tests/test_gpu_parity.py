@@ -516,6 +516,68 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu(tmp_path):
     assert out["rehearsal"]["reassembled_image_equals_whole_frame_render"] is True
     assert out["value"] > 0 and out["roofline"]["achieved_algorithmic_GBps"] > 0 and out["roofline"]["kernel_ms"] > 0
     assert out["rng_mode_1_same_sharding"]["value"] > 0              # both generators are reported for the sharded step
+    # what scales, readable without any other document: the three forms against their own one-GPU times measured in the same run
+    sd = out["scaling_detail"]
+    assert sd["n_gpus"] == 2 and set(sd["speedup_vs_1gpu"]) == {"single_launch_rng_mode_0", "single_launch_rng_mode_1", "batch_launch_rng_mode_0"}
+    assert all(v and v > 0 for v in sd["speedup_vs_1gpu"].values()), sd
+
+
+def test_bench_line_ties_the_headline_frame_to_the_oracle(tmp_path):
+    """`python bench.py` at N = 1 (a small frame here): the oracle rows rendered for the cpu_baseline leg are compared with the same rows of the
+    image of the timed GPU step, and the line says so -- `parity_rows.mismatched == 0`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--tris", "20000", "--width", "322", "--height", "190", "--spp", "16",
+           "--no-extras", "--no-pmc", "--cpu-budget", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    pr = out["parity_rows"]
+    assert pr["rows"] >= 8 and pr["pixels"] == pr["rows"] * 322 and pr["mismatched"] == 0 and pr["lit_pixels"] > 100, pr
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+
+
+def test_headline_mesh_rows_match_the_oracle(dsrt, gpu_ctx, oracle):
+    """The bench's own workload -- the 1,000,000-triangle stand-in, pose frame 98, 1920x1080, max_depth 50 -- at 48 samples: twelve rows spread
+    over the image against the oracle, rgb8 and fp32 bit patterns.  The tree of this mesh needs 18 stack entries: 10 spill levels behind the
+    8-entry LDS stack, which the small test meshes never reach."""
+    import threading
+    from dsrt_amd import meshgen
+    obj = f"/tmp/dsrt_bench_station_v{meshgen.VERSION}_1000000.obj"
+    if not os.path.exists(obj):
+        tmp = obj + f".{os.getpid()}.tmp"
+        meshgen.write_obj(meshgen.build_station(1000000), tmp, mtl_name=os.path.basename(obj)[:-4] + ".mtl")
+        os.replace(tmp, obj)
+    hs = dsrt.HostScene().add_obj(obj)
+    hs.build_bvh()
+    assert hs.stack_need > 8
+    poses = dsrt.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
+    W, H, spp = 1920, 1080, 48
+    fr = dsrt.pose_to_frame(poses[98])
+    cam = dsrt.frame_camera(fr, 40.0, W, H, spp, 50)
+    scene = hs.view(cam, tuple(fr.sun_dir_model))
+    scene.params.samples_per_pixel = spp
+    gpu_ctx.upload(scene)
+    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50), want_f32=True)
+    rows = [45 + 90 * k for k in range(12)]
+    want = np.zeros((H, W, 3), np.uint8)
+    want32 = np.zeros((H, W, 3), np.float32)
+    cnt = [(C.c_uint64 * len(oracle.COUNTER_NAMES))() for _ in rows]
+    threads = [threading.Thread(target=oracle.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y, y + 1, want.ctypes.data, want32.ctypes.data, cnt[i]))
+               for i, y in enumerate(rows)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    img_rows = [H - 1 - y for y in rows]
+    assert (want[img_rows].max(axis=2) > 0).sum() > 2000
+    assert np.array_equal(rgb[img_rows], want[img_rows]), f"{(rgb[img_rows] != want[img_rows]).any(axis=2).sum()} pixels differ"
+    assert np.array_equal(f32[img_rows].view(np.uint32), want32[img_rows].view(np.uint32))
+    # the counting build on this tree: the LDS stack's spill path is taken, and its maximum depth is the oracle's
+    _, _, sc = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 2, 50, collect_counters=2))
+    assert sc.stack_spills > 0 and sc.max_stack > 8
 
 
 def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
@@ -850,7 +912,8 @@ class DeviceMatkat:
         self.ctx = ctx
 
     @staticmethod
-    def _pack(n, **cols):
+    def _pack(rows, **cols):
+        n = rows
         a = np.zeros((n, 12), np.float32)
         for k, (col, val) in cols.items():
             val = np.asarray(val)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""The vector-ALU issue ceiling of this device (dsrt_microbench_valu): one JSON line per configuration.  GPU box only.
-  (default)      every kind at 4 and 8 waves per SIMD with all lanes live; v_fma_f32 also at 1 and 2; then v_fma_f32, v_pk_fma_f32 and the
-                 select at 4 waves per SIMD with partial lane masks (lower half, a quarter, even lanes, 25 scattered lanes, one lane)
-  --pmc          what the PMC pass watches (tools/valu_pmc.sh): every kind at 8 waves per SIMD, v_fma_f32 / v_pk_fma_f32 / the mix at 4"""
+"""What a vector-ALU instruction costs to issue on this device (dsrt_microbench_valu): one JSON line per configuration.  GPU box only.
+  (default)   every kind, 8 workgroups per CU, back to back (x32) and alternating with v_add_f32; the selects and compares also in pairs;
+              v_fma_f32 at 1 / 2 / 4 waves per SIMD; v_fma_f32, v_pk_fma_f32 and the select at 4 waves per SIMD with partial lane masks
+  --pmc       what the PMC pass watches (tools/valu_pmc.sh): every kind back to back, 8 workgroups per CU"""
 import json
 import os
 import sys
@@ -15,17 +15,19 @@ FULL = (1 << 64) - 1
 
 def main():
     import dsrt_amd as d
-    iters = 100000
+    iters = 60000
     kinds = range(len(d.VALU_KINDS))
     if "--pmc" in sys.argv:
-        cfgs = [(k, 8, FULL) for k in kinds] + [(k, 4, FULL) for k in (0, 1, 14)]
+        cfgs = [(k, 0, 8, FULL) for k in kinds]
     else:
-        cfgs = [(k, w, FULL) for k in kinds for w in (4, 8)] + [(0, 1, FULL), (0, 2, FULL)]
+        cfgs = [(k, p, 8, FULL) for k in kinds for p in (0, 1)]
+        cfgs += [(k, 2, 8, FULL) for k in kinds if "cndmask" in d.VALU_KINDS[k] or "cmp" in d.VALU_KINDS[k]]
+        cfgs += [(0, 0, w, FULL) for w in (1, 2, 4)]
         scattered = sum(1 << ((i * 37 + 11) & 63) for i in range(25))
         for mask in ((1 << 32) - 1, (1 << 16) - 1, 0x5555555555555555, scattered, 1):
-            cfgs += [(0, 4, mask), (1, 4, mask), (7, 4, mask)]
-    for kind, wps, mask in cfgs:
-        print(json.dumps(d.microbench_valu(kind, wps, iters, mask)), flush=True)
+            cfgs += [(0, 0, 4, mask), (1, 0, 4, mask), (7, 0, 4, mask)]
+    for kind, pattern, wps, mask in cfgs:
+        print(json.dumps(d.microbench_valu(kind, wps, iters, mask, pattern)), flush=True)
 
 
 if __name__ == "__main__":
