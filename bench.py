@@ -19,9 +19,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 roofline.  The path is branchy fp32 vector arithmetic over a scene that lives in L2 / Infinity Cache; the counters say it is bound
 by vector-ALU ISSUE (and, second, by the L1's request rate), not by HBM.  The object therefore carries
   bound / achieved / peak / frac   the binding resource: VALU wave-instructions per second of the render kernel (PMC SQ_INSTS_VALU
-                                   of this very run, rocprofv3 child pass) against the chip's issue ceiling, 1 wave64 VALU
-                                   instruction per SIMD per 4 cycles (measured by the library's calibration kernel on this device:
-                                   tools/gather_sweep.py --valu, profiles/r02/)
+                                   of this very run, rocprofv3 child pass) against the chip's issue PEAK, 1 wave64 VALU instruction
+                                   per SIMD per 2 cycles (the guide's SIMD-32 figure; `peak_basis` says so in the line).
+  issue_costs, mix                 what this device charges per instruction class, calibrated live (dsrt_microbench_valu), and what
+                                   the kernel's own instruction mix therefore allows: most of its stream (packed fp32, compares,
+                                   selects, min/max) issues at half the simple-op rate, so `valu_busy_estimate` -- issue cycles
+                                   spent / issue cycles available -- is the fraction that says how close to issue-bound it runs
+  useful_lane_frac                 frac x valu_lane_occupancy: lanes doing useful work per peak lane-slot
   l1                               16-byte L1 requests per second (PMC TCP_TOTAL_CACHE_ACCESSES) against the gather ceiling of the
                                    calibration kernel run live (dsrt_microbench_gather: same launch shape, every lane gathering random
                                    64-byte records as 4 x 16 B from an L2-resident table)
@@ -46,7 +50,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-VALU_CYCLES_PER_WAVE_INSTR = 4.0   # measured: 4 waves/SIMD of independent v_fma chains issue one instruction per SIMD per 4.5 cycles (profiles/r02)
+VALU_PEAK_CYCLES_PER_WAVE_INSTR = 2.0   # /opt/skills/guides/MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32 once a second wave
+                                        # is on the SIMD.  Measured here (dsrt_microbench_valu, profiles/r03/valu_issue_costs.md): v_add / v_mul / v_fma / v_mov /
+                                        # v_and 2.3-2.45 cycles; v_pk_*, v_cmp, v_cndmask_e64, v_min / v_max, shifts 4.1-4.4; v_rcp / v_sqrt 8.1-8.5.  Round 2
+                                        # priced the kernel against 4 cycles (cross-dependent fma chains): right for this kernel's MIX, wrong as the chip's peak.
+# VALU instruction classes of the production kernel's three hot loops, static counts weighted by the loops' trip counts (tools/isa_mix.py on this
+# build, profiles/r03/isa_mix.txt): share of simple-rate, half-rate and quarter-rate instructions in the issued stream
+KERNEL_VALU_CLASS_SHARES = {"simple": 0.22, "half": 0.70, "quarter": 0.08}
 RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0>"
 
 
@@ -815,15 +825,20 @@ def main():
         roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
                 "kernel": "dsrt_render_kernel", "kernel_ms": my_kernel_ms,
                 "achieved_algorithmic_GBps": my_bytes / secs / 1e9 if secs > 0 else None, "algorithmic_bytes_per_launch": my_bytes,
-                "note": "rank 0's launch. The kernel is bound by vector-ALU issue (one wave64 VALU instruction per SIMD per 4 cycles), second by the L1 request "
-                        "rate; HBM is nearly idle (the scene lives in L2 / Infinity Cache). achieved_algorithmic = SURVEY.md 8(d) bytes / kernel time counts "
-                        "every re-read the caches serve and is therefore not a fraction of the HBM peak; hbm.frac (PMC, this run) is."}
+                "note": "rank 0's launch. The kernel is bound by vector-ALU issue, second by the L1 request rate; HBM is nearly idle (the scene lives in L2 / "
+                        "Infinity Cache). frac is against the chip's simple-op issue peak (2 cycles per wave64 instruction per SIMD); mix.valu_busy_estimate prices the "
+                        "kernel's own instruction classes. achieved_algorithmic = SURVEY.md 8(d) bytes / kernel time counts every re-read the caches serve and is "
+                        "therefore not a fraction of the HBM peak; hbm.frac (PMC, this run) is."}
         if n_gpus == 1:
             cal = {}
             try:
                 g0 = d.microbench_gather(0, False, 64, 0, 2 << 20, 2000, device=local_rank)
                 g1 = d.microbench_gather(0, False, 64, 0, 19 << 20, 2000, device=local_rank)
                 cal = {"l1_requests16_per_s_G_ceiling": g0["Grecords_per_s"] * 4, "random_19MB_table_records_per_s_G": g1["Grecords_per_s"]}
+                simds_here = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+                cal["issue_costs_cycles_per_instruction_per_simd"] = {
+                    k: d.microbench_valu(k, 8, 20000, device=local_rank, simds=simds_here)["cycles_per_instruction_per_simd"]
+                    for k in ("v_add_f32", "v_fma_f32", "v_pk_mul_f32", "v_cndmask_b32_e64(sgpr pair)", "v_cmp_lt_f32_e64(sgpr pair)", "v_max_f32", "v_rcp_f32")}
             except d.DsrtError as e:
                 cal = {"error": str(e)[:160]}
             pmc = None
@@ -837,10 +852,24 @@ def main():
                 simds = props.multi_processor_count * 4
                 if pmc.get("SQ_INSTS_VALU") and clk:
                     roof["achieved"] = pmc["SQ_INSTS_VALU"] / secs / 1e9
-                    roof["peak"] = simds * clk / VALU_CYCLES_PER_WAVE_INSTR / 1e9
+                    roof["peak"] = simds * clk / VALU_PEAK_CYCLES_PER_WAVE_INSTR / 1e9
                     roof["frac"] = roof["achieved"] / roof["peak"]
+                    roof["peak_basis"] = ("1 wave64 VALU instruction per SIMD per 2 cycles (MI355X_MICROARCH.md, SIMD-32) x 1024 SIMDs x the shader clock of this launch "
+                                          "(GRBM_GUI_ACTIVE / 8 / kernel time); the best this device was measured to do is issue_costs['v_add_f32'] cycles (simple ops), and "
+                                          "most of this kernel's instructions are of the classes that cost twice that -- see mix")
                     roof["valu_lane_occupancy"] = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc.get("SQ_ACTIVE_INST_VALU", 1.0))
+                    roof["useful_lane_frac"] = roof["frac"] * roof["valu_lane_occupancy"]
                     roof["shader_clock_GHz"] = clk / 1e9
+                    costs = cal.get("issue_costs_cycles_per_instruction_per_simd") or {}
+                    if all(k in costs for k in ("v_add_f32", "v_pk_mul_f32", "v_rcp_f32")):
+                        half = sum(costs[k] for k in ("v_pk_mul_f32", "v_cndmask_b32_e64(sgpr pair)", "v_max_f32", "v_cmp_lt_f32_e64(sgpr pair)") if k in costs)
+                        half /= max(1, sum(1 for k in ("v_pk_mul_f32", "v_cndmask_b32_e64(sgpr pair)", "v_max_f32", "v_cmp_lt_f32_e64(sgpr pair)") if k in costs))
+                        avg = (KERNEL_VALU_CLASS_SHARES["simple"] * costs["v_add_f32"] + KERNEL_VALU_CLASS_SHARES["half"] * half +
+                               KERNEL_VALU_CLASS_SHARES["quarter"] * costs["v_rcp_f32"])
+                        roof["mix"] = {"class_shares_static": KERNEL_VALU_CLASS_SHARES, "average_issue_cycles_per_instruction": avg,
+                                       "valu_busy_estimate": pmc["SQ_INSTS_VALU"] * avg / (simds * clk * secs),
+                                       "frac_of_measured_simple_op_rate": roof["achieved"] / (simds * clk / costs["v_add_f32"] / 1e9),
+                                       "note": "valu_busy_estimate = issued instructions x the measured issue cost of their class / (SIMDs x cycles of the launch)"}
                 if pmc.get("TCP_TOTAL_CACHE_ACCESSES_sum") and cal.get("l1_requests16_per_s_G_ceiling"):
                     ach = pmc["TCP_TOTAL_CACHE_ACCESSES_sum"] / secs / 1e9
                     roof["l1"] = {"achieved": ach, "peak": cal["l1_requests16_per_s_G_ceiling"], "unit": "G 16-byte L1 requests/s", "frac": ach / cal["l1_requests16_per_s_G_ceiling"],

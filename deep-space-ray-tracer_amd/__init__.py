@@ -220,7 +220,7 @@ def microbench_valu(kind=0, waves_per_simd=8, iters=20000, lane_mask=(1 << 64) -
     _check(lib.dsrt_microbench_valu(int(device), int(kind), int(pattern), int(waves_per_simd), int(iters), int(lane_mask), C.byref(ms), C.byref(n), C.byref(ghz)),
            "dsrt_microbench_valu")
     gips = n.value / ms.value / 1e6
-    return {"kind": VALU_KINDS[kind], "pattern": ("x32", "alternating with v_add_f32", "pairs between pairs of v_add_f32")[pattern], "waves_per_simd": waves_per_simd, "iters": iters,
+    return {"kind": VALU_KINDS[kind], "pattern": ("x32", "alternating with v_add_f32", "pairs between pairs of v_add_f32", "x16 then v_add_f32 x16", "alternating with v_pk_mul_f32", "x16 then v_pk_mul_f32 x16")[pattern], "waves_per_simd": waves_per_simd, "iters": iters,
             "lanes": bin(lane_mask).count("1"), "ms": ms.value, "wave_instructions": n.value, "G_wave_instructions_per_s": gips, "shader_clock_GHz": ghz.value,
             "cycles_per_instruction_per_simd": simds * ghz.value / gips}
 

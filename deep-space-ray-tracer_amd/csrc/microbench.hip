@@ -112,7 +112,9 @@ gather_kernel(const float4* __restrict__ table, uint32_t n_rec, int iters, int l
 // wave per SIMD each; enough dynamic LDS per workgroup that no more fit) each run `iters` x 32 instructions from EIGHT INDEPENDENT
 // register streams (no instruction reads the result of any of the seven before it), written as inline assembly so that the instruction
 // counted is the instruction issued.  pattern 0: 32 x the instruction; pattern 1: 16 x (the instruction, then a v_add_f32 on another
-// stream) -- some kinds cost far more back to back than next to something else; pattern 2: 8 x (the instruction twice, v_add_f32 twice).
+// stream) -- some kinds cost far more back to back than next to something else; pattern 2: 8 x (the instruction twice, v_add_f32 twice);
+// pattern 3: 16 x the instruction, then 16 x v_add_f32 (does the order INSIDE a wave matter when eight waves share the SIMD?); pattern 4:
+// alternating with v_pk_mul_f32 (only for kinds on the scalar streams); pattern 5: 16 x the instruction, then 16 x v_pk_mul_f32.
 // Every wave stamps its loop with the shader-clock counter (s_memtime) and the 100 MHz wall clock (s_memrealtime); the host reports
 // instructions per second and the frequency the shader clock ran at, i.e. cycles per wave-instruction per SIMD.  The PMC route
 // (SQ_INSTS_VALU over GRBM_GUI_ACTIVE) is tools/valu_pmc.sh.  Kinds: kValuKindNames below.
@@ -149,8 +151,14 @@ const char* const kValuKindNames[kValuKinds] = {"v_fma_f32", "v_pk_fma_f32", "v_
                       OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7) OP(0) OP(1) DSRT_ADD(4) DSRT_ADD(5) OP(2) OP(3) DSRT_ADD(6) DSRT_ADD(7)
 #define DSRT_VALU_OPERANDS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) \
                            : "v"(m), "v"(c), "v"(pm), "v"(pc), "s"(smask) : "vcc", "s20", "s21"
+#define DSRT_PAT3(OP) DSRT_R8(OP) DSRT_R8(OP) DSRT_R8(DSRT_ADD) DSRT_R8(DSRT_ADD)
+#define DSRT_PKM(i) "v_pk_mul_f32 " P(i) ", " P(i) ", %18\n\t"
+#define DSRT_PAT4(OP) OP(0) DSRT_PKM(4) OP(1) DSRT_PKM(5) OP(2) DSRT_PKM(6) OP(3) DSRT_PKM(7) OP(0) DSRT_PKM(4) OP(1) DSRT_PKM(5) OP(2) DSRT_PKM(6) OP(3) DSRT_PKM(7) \
+                      OP(0) DSRT_PKM(4) OP(1) DSRT_PKM(5) OP(2) DSRT_PKM(6) OP(3) DSRT_PKM(7) OP(0) DSRT_PKM(4) OP(1) DSRT_PKM(5) OP(2) DSRT_PKM(6) OP(3) DSRT_PKM(7)
+#define DSRT_PAT5(OP) OP(0) OP(1) OP(2) OP(3) OP(0) OP(1) OP(2) OP(3) OP(0) OP(1) OP(2) OP(3) OP(0) OP(1) OP(2) OP(3) DSRT_R8(DSRT_PKM) DSRT_R8(DSRT_PKM)
 #define DSRT_VALU_ASM(OP) do { if (PATTERN == 0) asm volatile(DSRT_PAT0(OP) DSRT_VALU_OPERANDS); else if (PATTERN == 1) asm volatile(DSRT_PAT1(OP) DSRT_VALU_OPERANDS); \
-                               else asm volatile(DSRT_PAT2(OP) DSRT_VALU_OPERANDS); } while (0)
+                               else if (PATTERN == 2) asm volatile(DSRT_PAT2(OP) DSRT_VALU_OPERANDS); else if (PATTERN == 3) asm volatile(DSRT_PAT3(OP) DSRT_VALU_OPERANDS); \
+                               else if (PATTERN == 4) asm volatile(DSRT_PAT4(OP) DSRT_VALU_OPERANDS); else asm volatile(DSRT_PAT5(OP) DSRT_VALU_OPERANDS); } while (0)
 
 template <int KIND, int PATTERN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
@@ -353,7 +361,10 @@ hipError_t launch_valu(int kind, int pattern, int blocks, size_t lds, int iters,
     if (kind == KIND) {
         if (pattern == 0) return launch_valu_one<KIND, 0>(blocks, lds, iters, lane_mask, stamps, sink);
         if (pattern == 1) return launch_valu_one<KIND, 1>(blocks, lds, iters, lane_mask, stamps, sink);
-        return launch_valu_one<KIND, 2>(blocks, lds, iters, lane_mask, stamps, sink);
+        if (pattern == 2) return launch_valu_one<KIND, 2>(blocks, lds, iters, lane_mask, stamps, sink);
+        if (pattern == 3) return launch_valu_one<KIND, 3>(blocks, lds, iters, lane_mask, stamps, sink);
+        if (pattern == 4) return launch_valu_one<KIND, 4>(blocks, lds, iters, lane_mask, stamps, sink);
+        return launch_valu_one<KIND, 5>(blocks, lds, iters, lane_mask, stamps, sink);
     }
     if constexpr (KIND + 1 < kValuKinds) return launch_valu<KIND + 1>(kind, pattern, blocks, lds, iters, lane_mask, stamps, sink);
     return hipErrorInvalidValue;
@@ -436,7 +447,7 @@ extern "C" const char* dsrt_microbench_valu_kind_name(int kind) { return kind >=
 
 extern "C" int dsrt_microbench_valu(int device, int kind, int pattern, int waves_per_simd, int iters, uint64_t lane_mask, float* out_ms, double* out_wave_instructions,
                                     double* out_shader_clock_GHz) {
-    if (kind < 0 || kind >= kValuKinds || pattern < 0 || pattern > 2 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms ||
+    if (kind < 0 || kind >= kValuKinds || pattern < 0 || pattern > 5 || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || iters > (1 << 24) || lane_mask == 0 || !out_ms ||
         !out_wave_instructions || !out_shader_clock_GHz) {
         dsrt::set_error("dsrt_microbench_valu: bad argument");
         return DSRT_ERR_INVALID;

@@ -332,7 +332,8 @@ int dsrt_microbench_gather(int device, int mode, int dependent, int live_lanes, 
 
 /* The other calibration: what a vector-ALU instruction costs to issue.  `waves_per_simd` (1..8) workgroups per CU (one wave per SIMD each) each
  * issue iters x 32 instructions from eight independent register streams: pattern 0 = the instruction of `kind` 32 times, 1 = alternating with
- * v_add_f32, 2 = in pairs between pairs of v_add_f32 (some kinds cost far more back to back); only the lanes in `lane_mask` execute them.
+ * v_add_f32, 2 = in pairs between pairs of v_add_f32 (some kinds cost far more back to back), 3 = 16 of them then 16 v_add_f32, 4 / 5 = as 1 / 3
+ * with v_pk_mul_f32 as the partner; only the lanes in `lane_mask` execute them.
  * Returns the kernel time (HIP events), the wave-instructions issued and the shader clock during the run (the waves' s_memtime against the
  * 100 MHz s_memrealtime): cycles per instruction per SIMD = SIMDs x clock x time / instructions.  dsrt_microbench_valu_kinds /
  * _kind_name enumerate the kinds.  No reference interface: measurement only. */

@@ -17,7 +17,10 @@ def main():
     import dsrt_amd as d
     iters = 60000
     kinds = range(len(d.VALU_KINDS))
-    if "--pmc" in sys.argv:
+    if "--order" in sys.argv:            # does the order inside a wave matter?  4 and 8 workgroups per CU
+        pick = [k for k in kinds if d.VALU_KINDS[k] in ("v_cndmask_b32_e64(sgpr pair)", "v_max_f32", "v_cmp_lt_f32_e64(sgpr pair)", "v_pk_mul_f32", "v_min3_f32")]
+        cfgs = [(k, p, w, FULL) for k in pick for w in (4, 8) for p in (0, 1, 3, 4, 5) if not (d.VALU_KINDS[k].startswith("v_pk") and p >= 4)]
+    elif "--pmc" in sys.argv:
         cfgs = [(k, 0, 8, FULL) for k in kinds]
     else:
         cfgs = [(k, p, 8, FULL) for k in kinds for p in (0, 1)]
