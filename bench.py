@@ -54,9 +54,10 @@ VALU_PEAK_CYCLES_PER_WAVE_INSTR = 2.0   # /opt/skills/guides/MI355X_MICROARCH.md
                                         # is on the SIMD.  Measured here (dsrt_microbench_valu, profiles/r03/valu_issue_costs.md): v_add / v_mul / v_fma / v_mov /
                                         # v_and 2.3-2.45 cycles; v_pk_*, v_cmp, v_cndmask_e64, v_min / v_max, shifts 4.1-4.4; v_rcp / v_sqrt 8.1-8.5.  Round 2
                                         # priced the kernel against 4 cycles (cross-dependent fma chains): right for this kernel's MIX, wrong as the chip's peak.
-# VALU instruction classes of the production kernel's three hot loops, static counts weighted by the loops' trip counts (tools/isa_mix.py on this
-# build, profiles/r03/isa_mix.txt): share of simple-rate, half-rate and quarter-rate instructions in the issued stream
-KERNEL_VALU_CLASS_SHARES = {"simple": 0.22, "half": 0.70, "quarter": 0.08}
+# VALU instruction classes of the production kernel's three hot loops: static counts (tools/isa_mix.py --loops on this build) weighted by the loops'
+# shares of the issued stream, node loop 0.57 / leaf pass 0.21 / advance 0.22 (trip counts of the counting build x VALU per trip against SQ_INSTS_VALU;
+# profiles/r03/isa_mix.txt): share of simple-rate, half-rate and quarter-rate instructions
+KERNEL_VALU_CLASS_SHARES = {"simple": 0.27, "half": 0.66, "quarter": 0.07}
 RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0>"
 
 

@@ -3,7 +3,9 @@
 costs measured by dsrt_microbench_valu (tools/valu_ceiling.py, profiles/r03/valu_issue_costs.*): what the kernel's own instruction stream
 allows the vector ALU to issue per cycle.
 
-usage: hipcc ... --cuda-device-only -S -o render.s csrc/render_kernel.hip ; tools/isa_mix.py render.s 'ILi8ELb0ELb0ELb1ELi0' [--blocks LBB16_375 ...]
+usage: hipcc ... --cuda-device-only -S -o render.s csrc/render_kernel.hip ; tools/isa_mix.py render.s 'ILi8ELb0ELb0ELb1ELi0' [--blocks LBB16_375 ...] [--loops]
+--loops groups the blocks by the innermost loop the compiler's comments put them in (`in Loop: Header=...`), which is how the node loop, the plain leaf loop
+and the advance loop are told apart without knowing this build's label numbers.
 Classes (cycles per wave64 instruction per SIMD, 8 waves per SIMD, PMC):
   simple  2.4   v_add/sub/mul/fma/fmac/mov/and/or/xor/shift/add_u32 ...
   half    4.2   v_pk_*, v_cmp*, v_cndmask*, v_min*/v_max*/v_med3, v_bfi, 64-bit integer
@@ -34,11 +36,17 @@ def main():
     only = sys.argv[sys.argv.index("--blocks") + 1:] if "--blocks" in sys.argv else None
     lines = open(path).read().split("\n")
     start = [i for i, l in enumerate(lines) if l.startswith("_ZN4dsrt") and key in l and l.rstrip().split(";")[0].strip().endswith(":")][0]
-    name, tot, per_block = "entry", {}, {}
+    name, tot, per_block, loop_of, per_loop = "entry", {}, {}, {"entry": "(no loop)"}, {}
     for l in lines[start + 1:]:
         t = l.strip()
         if re.match(r"^\.LBB\S+:", t):
             name = t.split(":")[0].lstrip(".")
+            m = re.search(r"Header=(\S+) Depth=(\d+)", t)
+            if "Loop Header: Depth=" in t or "Inner Loop Header" in t:
+                d = re.search(r"Depth=(\d+)", t).group(1)
+                loop_of[name] = f"{name[1:]} depth {d}"
+            else:
+                loop_of[name] = f"{m.group(1)} depth {m.group(2)}" if m else "(no loop)"
             continue
         if not t or t[0] in ";.":
             continue
@@ -52,11 +60,17 @@ def main():
             tot[k] = tot.get(k, 0) + 1
         per_block.setdefault(name, {}).setdefault(k, 0)
         per_block[name][k] += 1
+        lp = per_loop.setdefault(loop_of.get(name, "(no loop)"), {})
+        lp[k] = lp.get(k, 0) + 1
     if only:
         for b in only:
             c = per_block.get(b, {})
             n = sum(c.values())
             print(b, c, "VALU", n, "cycles", round(sum(COST[k] * v for k, v in c.items()), 1))
+    if "--loops" in sys.argv:
+        for lp, c in sorted(per_loop.items(), key=lambda kv: -sum(kv[1].values())):
+            n = sum(c.values())
+            print(f"{lp:24s} VALU {n:5d}  simple {c.get('simple', 0):4d}  half {c.get('half', 0):4d}  quarter {c.get('quarter', 0):4d}  issue cycles {sum(COST[k] * v for k, v in c.items()):8.1f}")
     n = sum(tot.values())
     cyc = sum(COST[k] * v for k, v in tot.items())
     print("total" if only is None else "selected blocks", tot, "VALU", n, "issue cycles", round(cyc, 1), "average", round(cyc / max(1, n), 3), "cycles per instruction")
