@@ -307,8 +307,9 @@ bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
 
 // Development switches.  They are NOT part of the ABI (include/dsrt.h refuses unknown bits of DsrtRenderDesc.tune[3]); the A/B tools
 // under tools/ set them through the environment variable DSRT_EXPERIMENT (an integer in C syntax, read at every render call):
-//   1            leaf records are not dealt to idle lanes (render_kernel.hip, phase L)
 //   64           8 probe samples per pixel instead of 4
+//   128          leaf records are not dealt to idle lanes (render_kernel.hip, phase L)
+// (the low six bits are never used here: tools/ab_tune.py splits one number into the DSRT_TUNE_* flags and this word)
 //   bits 8-19    rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass)
 //   bits 20-22   grid = resident set >> n (frames that overlap on separate streams)
 //   bit 27       counting build of rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as bit patterns,
@@ -553,7 +554,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 16;
-    a.deal_leaves = (xp & 1u) ? 0 : 1;                          // (development switch 1: the leaf pass without dealing, for A/B runs)
+    a.deal_leaves = (xp & 128u) ? 0 : 1;                        // (development switch 128: the leaf pass without dealing, for A/B runs)
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | ((xp & (1u << 27)) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
