@@ -578,6 +578,31 @@ def test_headline_mesh_rows_match_the_oracle(dsrt, gpu_ctx, oracle):
     # the counting build on this tree: the LDS stack's spill path is taken, and its maximum depth is the oracle's
     _, _, sc = gpu_ctx.render_to_host(dsrt.make_desc(W, H, 2, 50, collect_counters=2))
     assert sc.stack_spills > 0 and sc.max_stack > 8
+    # and EVERY pixel of the frame at 4 samples (16 row bands in parallel; the C call releases the GIL), counters included
+    spp = 4
+    cam = dsrt.frame_camera(fr, 40.0, W, H, spp, 50)
+    scene = hs.view(cam, tuple(fr.sun_dir_model))
+    scene.params.samples_per_pixel = spp
+    gpu_ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, collect_counters=2), want_f32=True)
+    want = np.zeros((H, W, 3), np.uint8)
+    want32 = np.zeros((H, W, 3), np.float32)
+    bands = [(H * k // 16, H * (k + 1) // 16) for k in range(16)]
+    cnt = [(C.c_uint64 * len(oracle.COUNTER_NAMES))() for _ in bands]
+    threads = [threading.Thread(target=oracle.lib.dsrt_oracle_render_rows, args=(C.byref(scene), W, H, y0, y1, want.ctypes.data, want32.ctypes.data, cnt[i]))
+               for i, (y0, y1) in enumerate(bands)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert np.array_equal(rgb, want), f"{(rgb != want).any(axis=2).sum()} pixels differ"
+    assert np.array_equal(f32.view(np.uint32), want32.view(np.uint32))
+    tot = {n: sum(int(c[i]) for c in cnt) for i, n in enumerate(oracle.COUNTER_NAMES)}
+    for name in ("samples", "rays", "nodes_entered", "internal_entered", "tri_tests", "hit_updates", "box_fetches", "shaded_hits"):
+        assert getattr(st, name) == tot[name], (name, getattr(st, name), tot[name])
+    assert st.max_stack == max(int(c[oracle.COUNTER_NAMES.index("max_stack")]) for c in cnt)
+    rgb2, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50))                    # and the production build
+    assert np.array_equal(rgb2, want)
 
 
 def test_whole_1080p_frames_match_the_oracle(dsrt, gpu_ctx, oracle, tmp_path):
