@@ -858,6 +858,9 @@ def main():
                     roof["peak_basis"] = ("1 wave64 VALU instruction per SIMD per 2 cycles (MI355X_MICROARCH.md, SIMD-32) x 1024 SIMDs x the shader clock of this launch "
                                           "(GRBM_GUI_ACTIVE / 8 / kernel time); the best this device was measured to do is issue_costs['v_add_f32'] cycles (simple ops), and "
                                           "most of this kernel's instructions are of the classes that cost twice that -- see mix")
+                    roof["instructions_per_sample"] = pmc["SQ_INSTS_VALU"] / float(W * H * spp)       # wave-instructions per sample: the figure optimisation lowers while
+                    roof["frac_reading"] = ("frac is an issue RATE: a change that renders the frame with fewer instructions (round 3's leaf dealing: 241.7 -> 231.5 wave-"   # frac stands still
+                                            "instructions per sample) raises Msamples/s, lane occupancy and useful_lane_frac, not frac")
                     roof["valu_lane_occupancy"] = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc.get("SQ_ACTIVE_INST_VALU", 1.0))
                     roof["useful_lane_frac"] = roof["frac"] * roof["valu_lane_occupancy"]
                     roof["shader_clock_GHz"] = clk / 1e9

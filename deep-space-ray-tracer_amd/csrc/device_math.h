@@ -5,6 +5,17 @@
 #include "device_layout.h"
 #include "../../include/dsrt_detmath.h"
 
+#ifdef DSRT_DEVICE_LIBM
+// TEST BUILD ONLY (Makefile target `devlibm` -> oracle/_ref/libdsrt_hip_devlibm.so; never the product): the device math library's own sinf / cosf / powf
+// in place of include/dsrt_detmath.h.  These three functions are the one place where the product deliberately differs from what the reference's source
+// computes when the same compiler builds it (numerics contract); with this switch nothing differs, and the images of this build must
+// equal, byte for byte, those of the reference's own kernel translated by hipify-perl and run on the same GPU (oracle/_ref/ref_gpu,
+// tests/test_gpu_reference_kernel.py).
+#define dsrt_sinf(x) sinf(x)
+#define dsrt_cosf(x) cosf(x)
+#define dsrt_powf(x, y) powf(x, y)
+#endif
+
 namespace dsrt {
 
 // Wave votes straight from the compare mask (HIP's __ballot/__any/__all take an int and cost a v_cndmask + v_cmp each).
