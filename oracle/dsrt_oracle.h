@@ -29,13 +29,13 @@
  *         inc/material.h:28-32, 123-180, inc/onb.h:47-56; tests/golden/ref_matkat.json): bit for bit where
  *         the host arithmetic is float (everything but reflectance, which is double: to 3e-7); build_onb's u
  *         is the exact negative of the class's (cross(v, w) against cross(w, v)).
- *   - What remains **parity unpinned** against an execution of the reference is CONTROL FLOW AND ORDER ONLY:
- *     ray_color's sequence of decisions (:715-936: Russian roulette, sun NEE, the mixture branch, the
- *     per-sample clamp, which helper is called when and how many draws it takes), scene_hit's combination
- *     of BVH and spheres (:509-551) and the traversal ORDER of bvh_hit_closest (:387-473, which decides
- *     equal-distance ties).  Every arithmetic leaf those call is pinned above.  The control flow is a
- *     line-by-line restatement checked by review; src/gpu_render.cu needs nvcc and libcudart, which this
- *     image does not have, and no stand-in is written for them.
+ *   - CONTROL FLOW AND ORDER (ray_color :715-936, scene_hit :509-551, the traversal order of bvh_hit_closest :387-473) are pinned
+ *     one level up, by executing the reference's own kernel: oracle/_ref/ref_gpu (src/gpu_render.cu and src/gpu_scene_builder.cpp
+ *     translated CUDA -> HIP by the image's hipify-perl and compiled with hipcc, oracle/Makefile) renders the same bytes as the HIP
+ *     kernel built against the same device math library (tests/test_gpu_reference_kernel.py; the whole 1080p x 1000 spp headline
+ *     frame: profiles/r03/reference_kernel_hipified_headline_frame.json), and the HIP kernel's product build equals THIS restatement
+ *     bit for bit (tests/test_gpu_parity.py).  This file cannot be compared with ref_gpu directly -- it runs on the CPU and uses
+ *     dsrt_detmath.h where ref_gpu uses the device math library -- so its pin is that two-step chain plus the leaves above.
  *   - cosf/sinf/powf come from include/dsrt_detmath.h (shared with the HIP kernel), not from any
  *     libm: see that header.  Build with -DDSRT_ORACLE_LIBM to use the host libm instead (for the
  *     statistical comparison only).
