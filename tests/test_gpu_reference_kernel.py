@@ -41,11 +41,14 @@ def _read_ppm(path):
     return np.frombuffer(data[pos:pos + w * h * 3], np.uint8).reshape(h, w, 3)
 
 
-def _reference_image(name, tmp_path):
+REF_GPU_FMA = os.path.join(ROOT, "oracle", "_ref", "ref_gpu_fma")
+
+
+def _reference_image(name, tmp_path, exe=REF_GPU):
     world, cam_args, spp = CASES[name]
     (fx, fy, fz), (ax, ay, az), vfov, W, H, depth = cam_args
-    out = tmp_path / f"ref_{name}.ppm"
-    cmd = [REF_GPU, world + ".world", W, H, spp, depth, fx, fy, fz, ax, ay, az, vfov, *SUN, out]
+    out = tmp_path / f"ref_{name}_{os.path.basename(exe)}.ppm"
+    cmd = [exe, world + ".world", W, H, spp, depth, fx, fy, fz, ax, ay, az, vfov, *SUN, out]
     r = subprocess.run([str(c) for c in cmd], cwd=ASSETS, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     return _read_ppm(out)
@@ -143,3 +146,19 @@ def test_the_product_build_differs_from_the_reference_kernel_only_statistically(
     ours = _our_image(name, tmp_path).astype(np.int32)
     assert abs(float(ref.mean()) - float(ours.mean())) < 0.6                  # mean level within 0.6 / 255
     assert ((ref > 0).any(axis=2) == (ours > 0).any(axis=2)).mean() > 0.995  # the same pixels are lit
+
+
+def test_a_contracted_build_of_the_reference_is_the_same_picture_not_the_same_bytes(tmp_path):
+    """What parity with a real CUDA run can look like.  nvcc contracts a * b + c into one fused operation by default; oracle/_ref/ref_gpu_fma is the reference's
+    kernel compiled that way (-ffp-contract=fast, everything else as ref_gpu).  Against the strict build of the SAME source its image differs in some pixels -- one
+    rounding moves a sample across a branch and the rest of that pixel's random stream follows -- while mean level and coverage agree: the reason the product states
+    a bit-exact contract (the reference's operations, uncontracted) and calls the comparison with any contracted or other-libm build statistical."""
+    if not (os.path.exists(REF_GPU) and os.path.exists(REF_GPU_FMA)):
+        pytest.skip("oracle/_ref/ref_gpu or ref_gpu_fma not built")
+    name = "station_near"
+    strict = _reference_image(name, tmp_path).astype(np.int32)
+    fused = _reference_image(name, tmp_path, REF_GPU_FMA).astype(np.int32)
+    differing = float((strict != fused).any(axis=2).mean())
+    assert 0.0 < differing < 0.5, differing                                   # not the same bytes ...
+    assert abs(float(strict.mean()) - float(fused.mean())) < 0.6             # ... the same picture
+    assert ((strict > 0).any(axis=2) == (fused > 0).any(axis=2)).mean() > 0.995
