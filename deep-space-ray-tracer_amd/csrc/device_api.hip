@@ -439,17 +439,6 @@ int dsrt_shard_layout(const DsrtRenderDesc* desc, int* tiles_total, int* tiles_t
     return DSRT_OK;
 }
 
-// Ldir = f3_norm(f3_scale(sun_dir, -1)) of src/gpu_render.cu:802-806 (f3_norm :51-56), with the kernel's own float operations in the kernel's order
-// (this file is compiled with -ffp-contract=off; sqrtf and / are correctly rounded on both sides): the same three words the kernel used to form at
-// every shaded hit.
-static void light_direction(const DsrtF3& sun, float out[3]) {
-    const float x = -sun.x, y = -sun.y, z = -sun.z;
-    const float len = std::sqrt(x * x + y * y + z * z);
-    if (len <= 0.0f) { out[0] = out[1] = out[2] = 0.0f; return; }
-    const float inv = 1.0f / len;
-    out[0] = x * inv; out[1] = y * inv; out[2] = z * inv;
-}
-
 // What a batch launch adds to a render: the frames' cameras and sun directions (the context's own camera is not used).
 struct BatchInput { int frames; const GPUCamera* cameras; const DsrtF3* sun_dirs; };
 
@@ -478,7 +467,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         static_assert(sizeof cam12 == sizeof f.cam, "camera block");
         std::memcpy(f.cam, cam12, sizeof cam12);
     }
-    light_direction(ctx->sun_dir, f.light_dir);
+    f.sun_dir[0] = ctx->sun_dir.x; f.sun_dir[1] = ctx->sun_dir.y; f.sun_dir[2] = ctx->sun_dir.z;
     f.sun_radiance[0] = ctx->sun_radiance.x; f.sun_radiance[1] = ctx->sun_radiance.y; f.sun_radiance[2] = ctx->sun_radiance.z;
     f.sun_enabled = ctx->sun_enabled;
     f.width = desc->width; f.height = desc->height;
@@ -603,7 +592,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
                                      bc.horizontal.x, bc.horizontal.y, bc.horizontal.z, bc.vertical.x, bc.vertical.y, bc.vertical.z};
             static_assert(sizeof cam12 == sizeof e.cam, "camera block");
             std::memcpy(e.cam, cam12, sizeof cam12);
-            light_direction(batch->sun_dirs[i], e.light_dir);
+            e.sun_dir[0] = batch->sun_dirs[i].x; e.sun_dir[1] = batch->sun_dirs[i].y; e.sun_dir[2] = batch->sun_dirs[i].z;
             e.order_base = (uint32_t)(pre_stride * (size_t)i);
             e.image_slot = (uint32_t)i;
             ctx->batch_host[(size_t)frames + (size_t)i] = e;                                  // the frame's second entry (device_layout.h, BatchFrame)
@@ -618,7 +607,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             for (int i = 0; i < frames; ++i) {
                 RenderArgs pa = a;
                 std::memcpy(pa.frame.cam, ctx->batch_host[(size_t)i].cam, sizeof pa.frame.cam);
-                std::memcpy(pa.frame.light_dir, ctx->batch_host[(size_t)i].light_dir, 3 * sizeof(float));
+                std::memcpy(pa.frame.sun_dir, ctx->batch_host[(size_t)i].sun_dir, 3 * sizeof(float));
                 pa.frame.spp = 4; pa.frame.chunks = 1; pa.frame.chunk_len = 4;
                 pa.out_f32 = nullptr; pa.accum_fixed = nullptr; pa.counters = nullptr;
                 pa.sched = sched + pre_stride * (size_t)i;

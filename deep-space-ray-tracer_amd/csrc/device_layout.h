@@ -68,9 +68,7 @@ constexpr int kCamOrigin = 0, kCamLlc = 3, kCamHorizontal = 6, kCamVertical = 9;
 
 struct FrameParams {
     float cam[12];             // origin, lower-left corner, horizontal, vertical (kCamOrigin ... below), as GPUCamera has them
-    float light_dir[3];        // normalize(-sun_dir), the direction the sun term is evaluated along (src/gpu_render.cu:802-806): a frame constant, formed on the
-                               // host with the kernel's own float operations (device_api.hip, light_direction) instead of once per shaded hit
-    float sun_radiance[3];
+    float sun_dir[3], sun_radiance[3];
     int   sun_enabled;
     int   width, height, spp, max_depth;
     float inv_gamma;
@@ -94,7 +92,7 @@ struct FrameParams {
 // frame's pre-pass left in its `sched` words.
 struct BatchFrame {
     float    cam[12];          // as FrameParams::cam
-    float    light_dir[3];     // as FrameParams::light_dir
+    float    sun_dir[3];
     uint32_t item_end;         // work items of frames 0 .. this one (exclusive end of this frame's range in the batch queue)
     uint32_t order_base;       // where this frame's tile order starts in RenderArgs::batch_order
     uint32_t n_heavy, n_live;  // tiles that see geometry / tiles not proven empty

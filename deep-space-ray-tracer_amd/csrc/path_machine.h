@@ -262,7 +262,10 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     bool need_shadow = false;
                     F3 sh_o = mk(0, 0, 0), sh_d = mk(0, 0, 0);
                     if (P.sun_enabled) {
-                        const F3 Ldir = ld3(BATCH ? args.batch[ln.frame].light_dir : P.light_dir);      // normalize(-sun_dir) :802-806, formed once per frame on the host
+                        // (Forming Ldir once per frame on the host -- same float operations -- was tried in round 3: 30 instructions fewer per shaded hit and the
+                        //  frame 1 % SLOWER, 1056 -> 1067 ms in an interleaved A/B of the two builds: the register allocation around this block moved.  Left here.)
+                        const float* sun = BATCH ? args.batch[ln.frame].sun_dir : P.sun_dir;
+                        const F3 Ldir = normalize(mk(-sun[0], -sun[1], -sun[2]));
                         const float cos_t = fmaxf(0.0f, dot(hn, Ldir));
                         if (cos_t > 0.0f) {
                             sh_o = hp + (hn * 1e-3f);
