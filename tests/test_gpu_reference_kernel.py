@@ -162,3 +162,62 @@ def test_a_contracted_build_of_the_reference_is_the_same_picture_not_the_same_by
     assert 0.0 < differing < 0.5, differing                                   # not the same bytes ...
     assert abs(float(strict.mean()) - float(fused.mean())) < 0.6             # ... the same picture
     assert ((strict > 0).any(axis=2) == (fused > 0).any(axis=2)).mean() > 0.995
+
+
+def test_randomised_views_of_every_world_match_the_reference_kernel(tmp_path):
+    """A bounded fuzz of the executed pin: 30 random views over all six world files (spheres, lights with mixture sampling, metal, dielectric, textures, the
+    3k-triangle station, the `quirks` mesh with its degenerate and duplicated faces), ragged image sizes, 1 to 24 samples, depths 1 to 50, cameras from inside
+    the geometry to far outside, random un-normalised sun directions -- each rendered by the reference's own kernel (one ref_gpu process per view) and by this
+    kernel's device-libm build (one worker process for all), byte for byte."""
+    if not (os.path.exists(REF_GPU) and os.path.exists(DEVLIBM)):
+        pytest.skip("oracle/_ref/ref_gpu or libdsrt_hip_devlibm.so not built")
+    import json
+    rng = np.random.default_rng(20251005)
+    worlds = ("c1_spheres", "lights", "station_3k", "textured", "mixed", "quirks")
+    f32 = lambda v: float(np.float32(v))                      # noqa: E731 -- every number crosses both command lines as an exactly representable float
+    jobs = []
+    for trial in range(30):
+        world = worlds[trial % len(worlds)]
+        W, H = int(rng.integers(8, 150)), int(rng.integers(6, 100))
+        spp = int(rng.choice([1, 2, 5, 9, 24]))
+        depth = int(rng.choice([1, 2, 5, 12, 50]))
+        dist = float(rng.choice([0.5, 3.0, 9.0, 30.0, 120.0, 600.0])) * (0.15 if world in ("c1_spheres", "lights", "textured", "mixed") else 1.0)
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        jobs.append({"trial": trial, "world": world, "W": W, "H": H, "spp": spp, "depth": depth, "from": [f32(v) for v in direction * dist + (0.0, 1.0, 0.0)],
+                     "at": [f32(v) for v in rng.normal(size=3) * (0.0 if trial % 3 else 0.5)], "vfov": f32(rng.choice([20.0, 40.0, 75.0])),
+                     "sun": [f32(v) for v in rng.normal(size=3)], "out": str(tmp_path / f"ours_{trial}.rgb")})
+    (tmp_path / "jobs.json").write_text(json.dumps(jobs))
+    worker = (
+        "import sys, os, json\n"
+        "root, assets, jobs = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))\n"
+        "sys.path.insert(0, root)\n"
+        "import dsrt_amd as d\n"
+        "os.chdir(assets)\n"
+        "ctx, cache = d.Context(0), {}\n"
+        "for j in jobs:\n"
+        "    if j['world'] not in cache:\n"
+        "        hs = d.HostScene().add_world_file(j['world'] + '.world'); hs.build_bvh(); cache[j['world']] = hs\n"
+        "    hs = cache[j['world']]\n"
+        "    cam = d.camera_look_at(tuple(j['from']), tuple(j['at']), j['vfov'], j['W'], j['H'], j['spp'], j['depth'])\n"
+        "    ctx.upload(hs.view(cam, tuple(j['sun'])))\n"
+        "    rgb, _, _ = ctx.render_to_host(d.make_desc(j['W'], j['H'], j['spp'], j['depth']))\n"
+        "    open(j['out'], 'wb').write(rgb.tobytes())\n")
+    r = subprocess.run([sys.executable, "-c", worker, ROOT, ASSETS, str(tmp_path / "jobs.json")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DSRT_LIB=DEVLIBM))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    failures, lit_total = [], 0
+    for j in jobs:
+        ref_out = tmp_path / f"ref_{j['trial']}.ppm"
+        cmd = [REF_GPU, j["world"] + ".world", j["W"], j["H"], j["spp"], j["depth"], *[repr(v) for v in j["from"]], *[repr(v) for v in j["at"]], repr(j["vfov"]),
+               *[repr(v) for v in j["sun"]], ref_out]
+        rr = subprocess.run([str(c) for c in cmd], cwd=ASSETS, capture_output=True, text=True, timeout=600)
+        assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
+        ref = _read_ppm(ref_out)
+        ours = np.frombuffer(open(j["out"], "rb").read(), np.uint8).reshape(j["H"], j["W"], 3)
+        lit_total += int((ref.max(axis=2) > 0).sum())
+        bad = int((ref != ours).any(axis=2).sum())
+        if bad:
+            failures.append((j["trial"], j["world"], j["W"], j["H"], j["spp"], j["depth"], j["from"], bad))
+    assert not failures, failures
+    assert lit_total > 20000                                   # the views do see things
