@@ -35,7 +35,12 @@ $(BUILD)/hip_%.o: $(PKG)/csrc/%.hip $(HEADERS)
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(PKG)/libdsrt_hip.so: $(HOST_OBJ) $(HIP_OBJ)
+# csrc/render_kernel.hip is compiled twice: as it is, and with -DDSRT_DEVICE_LIBM (the kernels of DsrtRenderDesc.math_mode 1, in namespace dsrt::devlibm)
+$(BUILD)/hip_render_kernel_devlibm.o: $(PKG)/csrc/render_kernel.hip $(HEADERS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -DDSRT_DEVICE_LIBM -c $< -o $@
+
+$(PKG)/libdsrt_hip.so: $(HOST_OBJ) $(HIP_OBJ) $(BUILD)/hip_render_kernel_devlibm.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz -lrccl
 
 tools: $(PKG)/dsrt_render $(PKG)/main_flow_driver
@@ -46,23 +51,11 @@ $(PKG)/dsrt_render: $(PKG)/tools/dsrt_render.cpp $(PKG)/libdsrt_hip.so $(HEADERS
 $(PKG)/main_flow_driver: $(PKG)/tools/main_flow_driver.cpp $(PKG)/libdsrt_hip.so $(HEADERS)
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG) -ldsrt_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath-link,/opt/rocm/lib
 
-oracle: devlibm
+oracle:
 	$(MAKE) -C oracle all
-
-# TEST artefact (oracle/Makefile says what for): this library with the render kernels compiled against the device math library's own
-# sinf / cosf / powf instead of include/dsrt_detmath.h.  Never loaded by the product; lives beside the other checker binaries.
-devlibm: oracle/_ref/libdsrt_hip_devlibm.so
-
-$(BUILD)/hip_render_kernel_devlibm.o: $(PKG)/csrc/render_kernel.hip $(HEADERS)
-	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -DDSRT_DEVICE_LIBM -c $< -o $@
-
-oracle/_ref/libdsrt_hip_devlibm.so: $(HOST_OBJ) $(filter-out $(BUILD)/hip_render_kernel.o,$(HIP_OBJ)) $(BUILD)/hip_render_kernel_devlibm.o
-	@mkdir -p oracle/_ref
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -lz -lrccl
 
 clean:
 	rm -rf $(BUILD) $(PKG)/libdsrt_hip.so $(PKG)/dsrt_render $(PKG)/main_flow_driver
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib tools oracle devlibm clean
+.PHONY: all lib tools oracle clean

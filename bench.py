@@ -132,15 +132,15 @@ def cpu_baseline(d, scene, W, H, spp, budget_s, gpu_rgb8=None):
     return base, parity
 
 
-def reference_kernel_on_this_gpu(obj_path, fr, frame_idx, W, H, spp, our_ms_at_spp):
+def reference_kernel_on_this_gpu(d, ctx, part, stream, obj_path, fr, frame_idx, W, H, spp, depth):
     """The reference's OWN render kernel on this GPU, next to ours: oracle/_ref/ref_gpu is the reference's loader, build_gpu_scene and gpu_render_scene
     (src/gpu_render.cu), translated CUDA -> HIP by the image's hipify-perl and compiled with hipcc from the sources where they lie (oracle/Makefile; a
-    checker binary like oracle/_ref/ref_host, prebuilt, child process).  Same mesh, pose and size as the headline at a reduced sample count (its rate does
-    not depend on it: profiles/r03/reference_kernel_hipified_headline_frame.json has the full 1000 spp).  Two things come out of it, both outside every timed
-    region: its rate -- what "a hipify of src/gpu_render.cu" does on an MI355X -- and, with this kernel built against the same device math library
-    (oracle/_ref/libdsrt_hip_devlibm.so, a second child process), the number of pixels in which the two images differ."""
+    checker binary like oracle/_ref/ref_host, prebuilt, run as a child process).  Same mesh, pose and size as the headline at a reduced sample count (its rate
+    does not depend on it: profiles/r03/reference_kernel_hipified_headline_frame.json has the full 1000 spp).  Two things come out of it, both outside every
+    timed region: its rate -- what "a hipify of src/gpu_render.cu" does on an MI355X -- and the number of pixels in which its image differs from this
+    library's in math_mode 1 (the same kernels with the device math library's sinf / cosf / powf, as that build has them)."""
     import numpy as np
-    exe, devlibm = os.path.join(ROOT, "oracle", "_ref", "ref_gpu"), os.path.join(ROOT, "oracle", "_ref", "libdsrt_hip_devlibm.so")
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_gpu")
     if not os.path.exists(exe):
         return None
     tmp = tempfile.mkdtemp(prefix="dsrt_refgpu_", dir="/tmp")
@@ -149,36 +149,27 @@ def reference_kernel_on_this_gpu(obj_path, fr, frame_idx, W, H, spp, our_ms_at_s
         with open(world, "w") as f:
             f.write(f"obj {obj_path}\n")
         cam_from, sun = [repr(float(v)) for v in fr.cam_in_model], [repr(float(v)) for v in fr.sun_dir_model]
-        r = subprocess.run([exe, world, str(W), str(H), str(spp), "50", *cam_from, "0", "0", "0", "40", *sun, os.path.join(tmp, "ref.ppm"), "1"], cwd=tmp,
+        r = subprocess.run([exe, world, str(W), str(H), str(spp), str(depth), *cam_from, "0", "0", "0", "40", *sun, os.path.join(tmp, "ref.ppm"), "1"], cwd=tmp,
                            capture_output=True, text=True, timeout=600)
         ref = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         ms = ref["gpu_render_scene_second_call_ms"]
-        out = {"what": "the reference's loader + build_gpu_scene + gpu_render_scene, hipify-perl + hipcc (oracle/_ref/ref_gpu), second call on a resident scene, "
-                       "copy-back and PPM write included", "workload": f"{ref['triangles']} triangles, pose frame {frame_idx}, {W}x{H} @ {spp} spp, max_depth 50",
-               "gpu_render_scene_ms": ms, "Msamples/s": W * H * spp / ms / 1e3, "build_gpu_scene_ms": ref["build_gpu_scene_ms"],
-               "this_library_kernel_ms_same_frame": our_ms_at_spp, "this_library_is_faster_by": ms / our_ms_at_spp if our_ms_at_spp else None}
-        if os.path.exists(devlibm):
-            worker = ("import sys, os\nsys.path.insert(0, sys.argv[1])\nimport dsrt_amd as d\n"
-                      "obj, out, W, H, spp, frame = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])\n"
-                      "poses = d.read_pose_file(os.path.join(sys.argv[1], 'tests', 'golden', 'rendezvous_1s_dt0_01s.txt'))\nfr = d.pose_to_frame(poses[frame])\n"
-                      "hs = d.HostScene().add_obj(obj); hs.build_bvh()\ncam = d.frame_camera(fr, 40.0, W, H, spp, 50)\n"
-                      "ctx = d.Context(0); ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))\nrgb, _, _ = ctx.render_to_host(d.make_desc(W, H, spp, 50))\n"
-                      "open(out, 'wb').write(rgb.tobytes())\n")
-            ours = os.path.join(tmp, "ours.rgb")
-            rr = subprocess.run([sys.executable, "-c", worker, ROOT, obj_path, ours, str(W), str(H), str(spp), str(frame_idx)], capture_output=True, text=True,
-                                timeout=600, env=dict(os.environ, DSRT_LIB=devlibm))
-            if rr.returncode == 0:
-                data = open(os.path.join(tmp, "ref.ppm"), "rb").read()
-                header = f"P6\n{W} {H}\n255\n".encode()
-                ref_img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
-                our_img = np.frombuffer(open(ours, "rb").read(), np.uint8).reshape(H, W, 3)
-                out["image_comparison"] = {"pixels": W * H, "lit_pixels": int((ref_img.max(axis=2) > 0).sum()),
-                                           "differing_pixels": int((ref_img != our_img).any(axis=2).sum()),
-                                           "compared": "the reference kernel's image_gpu.ppm against this kernel built with the device math library's sinf / cosf / powf "
-                                                       "(libdsrt_hip_devlibm.so; the product uses include/dsrt_detmath.h for those three and equals the CPU oracle: parity_rows)"}
-            else:
-                out["image_comparison"] = {"error": (rr.stdout + rr.stderr)[-300:]}
-        return out
+        ours_ms = {}
+        for mode in (0, 1):
+            dsc = d.make_desc(W, H, spp, depth, math_mode=mode)
+            ctx.render(dsc, part.data_ptr(), stream=stream, want_stats=True)
+            ours_ms[mode] = ctx.render(dsc, part.data_ptr(), stream=stream, want_stats=True).kernel_ms
+        our_img = part[:W * H * 3].cpu().numpy().reshape(H, W, 3)                      # the math_mode 1 image
+        data = open(os.path.join(tmp, "ref.ppm"), "rb").read()
+        header = f"P6\n{W} {H}\n255\n".encode()
+        ref_img = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+        return {"what": "the reference's loader + build_gpu_scene + gpu_render_scene, hipify-perl + hipcc (oracle/_ref/ref_gpu), second call on a resident scene, "
+                        "copy-back and PPM write included", "workload": f"{ref['triangles']} triangles, pose frame {frame_idx}, {W}x{H} @ {spp} spp, max_depth {depth}",
+                "gpu_render_scene_ms": ms, "Msamples/s": W * H * spp / ms / 1e3, "build_gpu_scene_ms": ref["build_gpu_scene_ms"],
+                "this_library_kernel_ms_same_frame": {"math_mode_0": ours_ms[0], "math_mode_1": ours_ms[1]}, "this_library_is_faster_by": ms / ours_ms[0],
+                "image_comparison": {"pixels": W * H, "lit_pixels": int((ref_img.max(axis=2) > 0).sum()), "differing_pixels": int((ref_img != our_img).any(axis=2).sum()),
+                                     "compared": "the reference kernel's image_gpu.ppm against this library in math_mode 1 (the device math library's sinf / cosf / powf, as the "
+                                                 "reference's build has them; math_mode 0, the default, uses include/dsrt_detmath.h for those three and equals the CPU "
+                                                 "oracle: parity_rows), rgb8 bytes"}}
     except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported as such, it never stops the bench
         return {"error": str(e)[:300]}
     finally:
@@ -984,11 +975,7 @@ def main():
             out["cpu_baseline"], out["parity_rows"] = cpu_baseline(d, scene, W, H, spp, args.cpu_budget, gpu_rgb8=headline_image)
             if not args.no_extras:
                 out["cpu_baseline_book"] = book_baseline(obj, fr, host_cores(), os.path.join(ROOT, "gpurun_out", "timings_threads.tsv"))
-                ref_spp = min(spp, 100)
-                rdesc = d.make_desc(W, H, ref_spp, depth)
-                ctx.render(rdesc, part.data_ptr(), stream=stream, want_stats=True)
-                ours_ms = ctx.render(rdesc, part.data_ptr(), stream=stream, want_stats=True).kernel_ms
-                out["reference_kernel_on_this_gpu"] = reference_kernel_on_this_gpu(obj, fr, args.frame, W, H, ref_spp, ours_ms)
+                out["reference_kernel_on_this_gpu"] = reference_kernel_on_this_gpu(d, ctx, part, stream, obj, fr, args.frame, W, H, min(spp, 100), depth)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

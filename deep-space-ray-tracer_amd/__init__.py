@@ -177,10 +177,11 @@ def write_png(path, rgb, width, height):
 
 
 def make_desc(width, height, spp, max_depth=50, gamma=2.0, seed=1337, tile_size=0, shard_rank=0, shard_count=0,
-              collect_counters=0, checked=0, stack_entries=0, tune=(0, 0, 0, 0), rng_mode=0):
+              collect_counters=0, checked=0, stack_entries=0, tune=(0, 0, 0, 0), rng_mode=0, math_mode=0):
     d = DsrtRenderDesc()
     d.width, d.height, d.spp, d.max_depth, d.gamma, d.seed = int(width), int(height), int(spp), int(max_depth), float(gamma), int(seed)
     d.rng_mode = int(rng_mode)
+    d.math_mode = int(math_mode)
     d.tile_size, d.shard_rank, d.shard_count = int(tile_size), int(shard_rank), int(shard_count)
     d.collect_counters, d.checked, d.stack_entries = int(collect_counters), int(checked), int(stack_entries)
     for i, v in enumerate(tuple(tune) + (0,) * (4 - len(tune))):

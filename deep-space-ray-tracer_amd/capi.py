@@ -81,7 +81,7 @@ class DsrtRenderDesc(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int), ("gamma", C.c_float),
                 ("seed", C.c_uint64), ("rng_mode", C.c_int), ("tile_size", C.c_int), ("shard_rank", C.c_int),
                 ("shard_count", C.c_int), ("collect_counters", C.c_int), ("checked", C.c_int), ("stack_entries", C.c_int),
-                ("tune", C.c_int * 4)]
+                ("tune", C.c_int * 4), ("math_mode", C.c_int)]
 
 
 class DsrtStats(C.Structure):

@@ -39,6 +39,13 @@ hipError_t launch_tile_order(const DeviceScene& S, const FrameParams& P, uint32_
                              uint32_t resident_lanes, bool cull, hipStream_t stream, const BatchFrame* batch = nullptr, uint32_t frames = 1, uint32_t stride = 0);
 hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* tmp, const uint32_t* sched, hipStream_t stream);
 hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
+// DsrtRenderDesc.math_mode 1: the same kernels compiled against the device math library's sinf / cosf / powf (render_kernel.hip, second compilation)
+namespace devlibm {
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
+hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream);
+hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
+}  // namespace devlibm
 }  // namespace dsrt
 
 using namespace dsrt;
@@ -446,6 +453,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     if (!ctx || !desc || !d_rgb8) { set_error("dsrt_render: null argument"); return DSRT_ERR_INVALID; }
     if (!ctx->scene || !ctx->scene->valid) { set_error("dsrt_render: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
     if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
+    if (desc->math_mode != 0 && desc->math_mode != 1) { set_error("dsrt_render: math_mode must be 0 (deterministic sin / cos / pow shared with the CPU oracle) or 1 (the device math library's)"); return DSRT_ERR_INVALID; }
+    const bool libm = desc->math_mode == 1;
     if (desc->tune[3] & ~DSRT_TUNE_FLAG_MASK) { set_error("dsrt_render: tune[3] has bits set that this ABI version does not define (DSRT_TUNE_* in include/dsrt.h)"); return DSRT_ERR_INVALID; }
     const uint32_t flags = (uint32_t)desc->tune[3];
     const uint32_t xp = experiment_word();
@@ -617,7 +626,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
                 HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
                 HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
                 HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
-                HIP_TRY(launch_probe(pa, blocks, stream));
+                HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, stream) : launch_probe(pa, blocks, stream));
                 HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p + pre_stride * (size_t)i, ctx->tile_tmp.p, sched + pre_stride * (size_t)i, stream));
             }
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
@@ -654,7 +663,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
             pa.probe_queue = ctx->probe_queue.p;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
-            HIP_TRY(launch_probe(pa, blocks, stream));
+            HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, stream) : launch_probe(pa, blocks, stream));
             HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, stream));
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
         }
@@ -666,9 +675,11 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    if (batch) HIP_TRY(launch_render_batch(a, desc->rng_mode, blocks, stream));
+    if (batch) HIP_TRY(libm ? devlibm::launch_render_batch(a, desc->rng_mode, blocks, stream) : launch_render_batch(a, desc->rng_mode, blocks, stream));
+    else if (libm) HIP_TRY(devlibm::launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
     else HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
-    if (desc->rng_mode == 1) HIP_TRY(launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
+    if (desc->rng_mode == 1) HIP_TRY(libm ? devlibm::launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream)
+                                          : launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));
     ctx->done_valid = true;
     if (stats) {

@@ -6,11 +6,10 @@
 #include "../../include/dsrt_detmath.h"
 
 #ifdef DSRT_DEVICE_LIBM
-// TEST BUILD ONLY (Makefile target `devlibm` -> oracle/_ref/libdsrt_hip_devlibm.so; never the product): the device math library's own sinf / cosf / powf
-// in place of include/dsrt_detmath.h.  These three functions are the one place where the product deliberately differs from what the reference's source
-// computes when the same compiler builds it (numerics contract); with this switch nothing differs, and the images of this build must
-// equal, byte for byte, those of the reference's own kernel translated by hipify-perl and run on the same GPU (oracle/_ref/ref_gpu,
-// tests/test_gpu_reference_kernel.py).
+// Second compilation of render_kernel.hip (Makefile: hip_render_kernel_devlibm.o; DsrtRenderDesc.math_mode 1): the device math library's own sinf / cosf /
+// powf in place of include/dsrt_detmath.h.  These three functions are the one place where the default mode deliberately differs from what the reference's
+// source computes when the same compiler builds it (numerics contract); in this compilation nothing differs, and its images equal, byte
+// for byte, those of the reference's own kernel translated by hipify-perl and run on the same GPU (oracle/_ref/ref_gpu, tests/test_gpu_reference_kernel.py).
 #define dsrt_sinf(x) sinf(x)
 #define dsrt_cosf(x) cosf(x)
 #define dsrt_powf(x, y) powf(x, y)

@@ -32,6 +32,12 @@
 #include "path_machine.h"
 
 namespace dsrt {
+#ifdef DSRT_DEVICE_LIBM
+// Second compilation of this file (Makefile: hip_render_kernel_devlibm.o): the kernels whose arithmetic involves sinf / cosf / powf, built with the device math
+// library's versions (device_math.h) and put in a namespace of their own -- DsrtRenderDesc.math_mode 1.  Everything that does not depend on those three functions
+// (pre-pass, table, de-interleave, hash, test hooks) is compiled once, in the first pass.
+namespace devlibm {
+#endif
 constexpr int kWavesPerBlock = 4;
 // Register budget: 4 waves per SIMD (= 4 blocks per CU, which is also what the blocks' 31 KB of LDS allow).
 #ifndef DSRT_WAVES_ATTR
@@ -334,6 +340,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_rend
 
 // Fills the count fields of the batch table (entries f and frames + f belong to frame f) from the sched words every frame's pre-pass
 // wrote (sched_stride apart), and the running item totals.
+#ifndef DSRT_DEVICE_LIBM
 __global__ void dsrt_batch_table_kernel(BatchFrame* __restrict__ table, const uint32_t* __restrict__ sched, uint32_t sched_stride, uint32_t frames,
                                         uint32_t tt, int rng_mode, int spp, int light_chunk_len, uint32_t* __restrict__ total_items) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -354,12 +361,15 @@ __global__ void dsrt_batch_table_kernel(BatchFrame* __restrict__ table, const ui
     *total_items = acc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)acc;
 }
 
+#endif  // !DSRT_DEVICE_LIBM
+
 // The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
 // tile's entry of args.tile_work.  Its own kernel symbol, so that profiles keep it apart from the frame's launch.
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_probe_kernel(const RenderArgs args) {
     render_body<8, false, false, true, 0, true>(args);
 }
 
+#ifndef DSRT_DEVICE_LIBM
 // ---------------------------------------------------------------------------------------------------------------
 // Scheduling pre-pass: how expensive is each screen tile?  One wave per 8x8 pixel block traces the un-jittered centre
 // ray of every pixel with an any-hit walk; the tile's cost is the number of pixels that see geometry.  The render
@@ -626,6 +636,8 @@ hipError_t launch_devkat(int fn, const float* in, float* out, int n, hipStream_t
     return hipGetLastError();
 }
 
+#endif  // !DSRT_DEVICE_LIBM
+
 // rng_mode 1: a pixel's samples were summed as integers in units of 2^-20 (path_machine.h, end_sample); here the mean, the
 // reference's tone map and the 8-bit store (:1003-1030).  Pixels nobody sampled (culled tiles, padding) hold zero sums: black.
 __global__ void dsrt_resolve_kernel(const unsigned long long* __restrict__ sums, int spp, float inv_gamma, size_t n_pixels,
@@ -666,11 +678,14 @@ hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hi
     return hipGetLastError();
 }
 
+#ifndef DSRT_DEVICE_LIBM
 hipError_t launch_batch_table(BatchFrame* table, const uint32_t* sched, uint32_t sched_stride, uint32_t frames, uint32_t tt, int rng_mode, int spp, int light_chunk_len,
                               uint32_t* total_items, hipStream_t stream) {
     hipLaunchKernelGGL(dsrt_batch_table_kernel, dim3(1), dim3(64), 0, stream, table, sched, sched_stride, frames, tt, rng_mode, spp, light_chunk_len, total_items);
     return hipGetLastError();
 }
+
+#endif
 
 hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(dsrt_probe_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
@@ -689,6 +704,7 @@ hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gam
     return hipGetLastError();
 }
 
+#ifndef DSRT_DEVICE_LIBM
 // Test hook: the first n words of Philox sub-sequence `sub` from our stateless form and from rocRAND's own device engine.
 __global__ void dsrt_philox_kernel(unsigned long long seed, unsigned long long sub, int n, uint32_t* __restrict__ ours, uint32_t* __restrict__ theirs) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -743,4 +759,9 @@ hipError_t launch_math(int fn, const float* x, float y, float* out, int n, hipSt
 
 int kernel_waves_per_block() { return kWavesPerBlock; }
 
+#endif  // !DSRT_DEVICE_LIBM
+
+#ifdef DSRT_DEVICE_LIBM
+}  // namespace devlibm
+#endif
 }  // namespace dsrt

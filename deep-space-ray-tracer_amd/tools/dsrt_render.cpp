@@ -25,7 +25,7 @@ static int fail(const char* what) {
 
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
-    int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0;
+    int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0, math_mode = 0;
     bool sah = false, lbvh = false, png = false, strict_textures = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -45,10 +45,11 @@ int main(int argc, char** argv) {
         else if (a == "--fast") { sah = true; rng_mode = 1; }      // non-parity fast mode: SAH tree + Philox stream per sample (include/dsrt.h)
         else if (a == "--bvh") { const std::string k = next("--bvh"); sah = k == "sah"; lbvh = k == "lbvh"; }      // lbvh: built on the GPU (milliseconds), non-parity like sah
         else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
+        else if (a == "--reference-math") math_mode = 1;          // sinf / cosf / powf from the device math library: the reference's own kernel's bytes on this GPU (include/dsrt.h)
         else if (a == "--strict-textures") strict_textures = true;  // refuse a mesh whose texture maps this library cannot decode (include/dsrt.h)
         else if (a == "--png") png = true;                          // frames as PNG instead of PPM (the reference converts with ImageMagick)
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah|lbvh] [--rng-mode 0|1] [--fast] [--png] [--strict-textures]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah|lbvh] [--rng-mode 0|1] [--reference-math] [--fast] [--png] [--strict-textures]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -118,7 +119,7 @@ int main(int argc, char** argv) {
     }
     DsrtRenderDesc d;
     std::memset(&d, 0, sizeof d);
-    d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337; d.rng_mode = rng_mode;
+    d.width = width; d.height = height; d.spp = spp; d.max_depth = depth; d.gamma = 2.0f; d.seed = 1337; d.rng_mode = rng_mode; d.math_mode = math_mode;
     const size_t image_bytes = (size_t)width * height * 3;
     size_t per_launch = 32;
     while (per_launch > 1 && (unsigned long long)per_launch * width * height * (rng_mode == 1 ? 16ull : 1ull) >= (1ull << 32)) per_launch /= 2;

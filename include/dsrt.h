@@ -34,9 +34,9 @@ extern "C" {
 const char* dsrt_last_error(void);
 /* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
  * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
- * refused; dsrt_selftest_devkat, dsrt_microbench_valu).  dsrt_abi_version() returns the value the library was compiled with;
+ * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
-#define DSRT_ABI_VERSION 4
+#define DSRT_ABI_VERSION 5
 int dsrt_abi_version(void);
 
 /* ===================================================================================== */
@@ -187,6 +187,14 @@ typedef struct DsrtRenderDesc {
                                        two bits choose the pre-pass, the others switch one scheduling measure off each.  Any other bit is
                                        refused (DSRT_ERR_INVALID): development switches are not part of this ABI -- they are read from the
                                        environment variable DSRT_EXPERIMENT (csrc/device_api.hip) */
+    int      math_mode;             /* where sinf / cosf / powf come from -- the three library functions of the path (src/gpu_render.cu:104-106, 157-158, 211,
+                                       1019-1021).  0 (default): include/dsrt_detmath.h, built from correctly rounded operations only and shared with the CPU
+                                       oracle: the image is a function of the inputs alone, the same on the GPU and on a CPU, and what every parity test
+                                       against the oracle uses.  1: the device math library's own (what the reference's source gets when hipcc compiles it
+                                       for this GPU): the image is then, byte for byte, the one the reference's own kernel renders on the same GPU
+                                       (oracle/_ref/ref_gpu; tests/test_gpu_reference_kernel.py).  The two modes differ in the last place of those three
+                                       functions and therefore, one LCG stream per pixel being what it is, in individual pixels; statistically they are
+                                       the same picture.  rng_mode and math_mode are independent */
 } DsrtRenderDesc;
 
 #define DSRT_TUNE_NATURAL_ORDER   1    /* tiles in natural order, no empty-tile culling (no pre-pass at all)                   */

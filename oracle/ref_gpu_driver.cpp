@@ -13,9 +13,9 @@
 // line of the reference's arithmetic or control flow is touched: the translator renames runtime API calls and includes.
 //
 // What it is for: the one thing nothing else in this pipeline could do -- EXECUTE ray_color, scene_hit and bvh_hit_closest as the reference
-// wrote them.  tests/test_gpu_reference_kernel.py renders the test scenes with this binary and with libdsrt_hip built against the same
-// device math library (oracle/_ref/libdsrt_hip_devlibm.so: csrc/ compiled with -DDSRT_DEVICE_LIBM, i.e. the platform's sinf / cosf / powf
-// where the product uses include/dsrt_detmath.h) and compares the images byte for byte.
+// wrote them.  tests/test_gpu_reference_kernel.py renders the test scenes with this binary and with libdsrt_hip in math_mode 1 (the same kernels
+// compiled with the platform's sinf / cosf / powf, which is what this build gets, where the default mode uses include/dsrt_detmath.h) and compares
+// the images byte for byte.
 //
 // usage: ref_gpu <world.txt> W H spp max_depth  from_x from_y from_z  at_x at_y at_z  vfov  sun_x sun_y sun_z  <out.ppm> [1 = render twice and time the second call]
 #define main dsrt_unused_reference_main

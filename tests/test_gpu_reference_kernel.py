@@ -4,11 +4,11 @@ oracle/_ref/ref_gpu is the reference's complete renderer (its OBJ / world loader
 ray_color -> scene_hit -> bvh_hit_closest, src/gpu_render.cu:387-1108), built by oracle/Makefile from the sources where they lie: the three files
 that name the CUDA runtime are translated to HIP by the image's own hipify-perl in a scratch directory and compiled with hipcc for gfx950 (no line
 of arithmetic or control flow is touched; oracle/ref_gpu_driver.cpp has the details).  What such a build cannot share with the product is the
-three library functions the product replaces by include/dsrt_detmath.h (sinf, cosf, powf: DESIGN.md section 2); so the product's kernel is built
-once more with exactly those three taken from the device math library (oracle/_ref/libdsrt_hip_devlibm.so, -DDSRT_DEVICE_LIBM) -- and then the two
-programs compute, operation for operation, the same thing, and their images must be equal BYTE FOR BYTE: every scene of the parity suite, ties,
-traversal order, Russian roulette, the mixture branch, dielectrics, textures and all.  The product build itself (detmath) equals the CPU oracle
-bit for bit (tests/test_gpu_parity.py); the two builds differ in those three functions only.
+three library functions the product replaces by include/dsrt_detmath.h by default (sinf, cosf, powf: DESIGN.md section 2); DsrtRenderDesc.math_mode 1
+selects the same kernels compiled with exactly those three taken from the device math library -- and then the two programs compute, operation for
+operation, the same thing, and their images must be equal BYTE FOR BYTE: every scene of the parity suite, ties, traversal order, Russian roulette,
+the mixture branch, dielectrics, textures and all.  math_mode 0 equals the CPU oracle bit for bit (tests/test_gpu_parity.py); the two modes are one
+source compiled twice and differ in those three functions only.  Everything here goes through the product library's C ABI.
 """
 import os
 import subprocess
@@ -17,14 +17,13 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ASSETS
+from conftest import ASSETS, load_world
 from test_oracle import CASES, SUN
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_GPU = os.path.join(ROOT, "oracle", "_ref", "ref_gpu")
-DEVLIBM = os.path.join(ROOT, "oracle", "_ref", "libdsrt_hip_devlibm.so")
 
 
 def _read_ppm(path):
@@ -54,26 +53,22 @@ def _reference_image(name, tmp_path, exe=REF_GPU):
     return _read_ppm(out)
 
 
-def _our_image(name, tmp_path, lib=None):
+def _our_image(dsrt, gpu_ctx, name, math_mode):
     world, cam_args, spp = CASES[name]
-    W, H = cam_args[3], cam_args[4]
-    out = tmp_path / f"ours_{name}_{'devlibm' if lib else 'product'}.rgb"
-    env = dict(os.environ)
-    if lib:
-        env["DSRT_LIB"] = lib
-    else:
-        env.pop("DSRT_LIB", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_render_case_worker.py"), name, str(out)], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    return np.frombuffer(open(out, "rb").read(), np.uint8).reshape(H, W, 3)
+    hs = load_world(dsrt, world)
+    W, H, depth = cam_args[3], cam_args[4], cam_args[5]
+    cam = dsrt.camera_look_at(cam_args[0], cam_args[1], cam_args[2], W, H, spp, depth)
+    gpu_ctx.upload(hs.view(cam, SUN))
+    rgb, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, math_mode=math_mode))
+    return rgb
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_reference_kernel_and_this_kernel_give_the_same_bytes(name, tmp_path):
-    if not (os.path.exists(REF_GPU) and os.path.exists(DEVLIBM)):
-        pytest.skip("oracle/_ref/ref_gpu or libdsrt_hip_devlibm.so not built (oracle/Makefile builds them where /root/reference and hipify-perl exist)")
+def test_reference_kernel_and_this_kernel_give_the_same_bytes(dsrt, gpu_ctx, name, tmp_path):
+    if not os.path.exists(REF_GPU):
+        pytest.skip("oracle/_ref/ref_gpu not built (oracle/Makefile builds it where /root/reference and hipify-perl exist)")
     ref = _reference_image(name, tmp_path)
-    ours = _our_image(name, tmp_path, DEVLIBM)
+    ours = _our_image(dsrt, gpu_ctx, name, 1)
     assert ref.shape == ours.shape
     lit = int((ref.max(axis=2) > 0).sum())
     assert lit > 150, "the reference's image should not be empty"
@@ -82,15 +77,13 @@ def test_reference_kernel_and_this_kernel_give_the_same_bytes(name, tmp_path):
 
 
 @pytest.mark.parametrize("tris,W,H,spp,frames", [(100000, 640, 360, 32, (98, 60)), (1000000, 1920, 1080, 12, (98,))])
-def test_reference_kernel_on_the_bench_mesh_pose_frames(tmp_path, tris, W, H, spp, frames):
+def test_reference_kernel_on_the_bench_mesh_pose_frames(dsrt, gpu_ctx, tmp_path, tris, W, H, spp, frames):
     """The bench's own kind of workload through both programs: the procedural station at 100,000 triangles, pose frames 98 (camera 36 m from the station, which
     fills the view) and 60 (715 m) of the reference's pose file, 640 x 360 at 32 samples; and THE BENCH'S MESH -- 1,000,308 triangles, a tree that needs 18 stack
     entries -- at the bench's size, frame 98, 12 samples; max_depth 50 -- every byte.  (The whole headline frame at 1000 samples: tools/reference_kernel_probe.py
     --spp 1000 --compare, profiles/r03/reference_kernel_hipified_headline_frame.json: 0 of 2,073,600 pixels differ.)"""
-    if not (os.path.exists(REF_GPU) and os.path.exists(DEVLIBM)):
-        pytest.skip("oracle/_ref/ref_gpu or libdsrt_hip_devlibm.so not built")
-    sys.path.insert(0, ROOT)
-    import dsrt_amd as d                                      # (host-side helpers only: mesh writer, pose arithmetic; no GPU call in this process)
+    if not os.path.exists(REF_GPU):
+        pytest.skip("oracle/_ref/ref_gpu not built")
     from dsrt_amd import meshgen
     from conftest import GOLDEN
     if tris == 1000000:                                       # the file bench.py and test_headline_mesh_rows_match_the_oracle use
@@ -103,47 +96,36 @@ def test_reference_kernel_on_the_bench_mesh_pose_frames(tmp_path, tris, W, H, sp
         obj = tmp_path / f"station_{tris}.obj"
         meshgen.generate(obj, tris)
     (tmp_path / "station.world").write_text(f"obj {obj}\n")
-    poses = d.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
+    hs = dsrt.HostScene().add_obj(obj)
+    hs.build_bvh()
+    assert hs.stack_need > 8
+    poses = dsrt.read_pose_file(os.path.join(GOLDEN, "rendezvous_1s_dt0_01s.txt"))
     depth = 50
-    worker = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, sys.argv[1])\n"
-        "import dsrt_amd as d\n"
-        "world, out = sys.argv[2], sys.argv[3]\n"
-        "W, H, spp, depth = (int(v) for v in sys.argv[4:8])\n"
-        "cam_from = tuple(float(v) for v in sys.argv[8:11]); sun = tuple(float(v) for v in sys.argv[11:14])\n"
-        "hs = d.HostScene().add_world_file(world); hs.build_bvh()\n"
-        "assert hs.stack_need > 8\n"
-        "cam = d.camera_look_at(cam_from, (0.0, 0.0, 0.0), 40.0, W, H, spp, depth)\n"
-        "ctx = d.Context(0); ctx.upload(hs.view(cam, sun))\n"
-        "rgb, _, _ = ctx.render_to_host(d.make_desc(W, H, spp, depth))\n"
-        "open(out, 'wb').write(rgb.tobytes())\n")
     for frame in frames:
-        fr = d.pose_to_frame(poses[frame])
+        fr = dsrt.pose_to_frame(poses[frame])
         cam_from, sun = [repr(float(v)) for v in fr.cam_in_model], [repr(float(v)) for v in fr.sun_dir_model]
-        ref_out, our_out = tmp_path / f"ref_{frame}.ppm", tmp_path / f"ours_{frame}.rgb"
+        ref_out = tmp_path / f"ref_{frame}.ppm"
         r = subprocess.run([REF_GPU, str(tmp_path / "station.world"), str(W), str(H), str(spp), str(depth), *cam_from, "0", "0", "0", "40", *sun, str(ref_out)],
                            cwd=tmp_path, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-        r = subprocess.run([sys.executable, "-c", worker, ROOT, str(tmp_path / "station.world"), str(our_out), str(W), str(H), str(spp), str(depth), *cam_from, *sun],
-                           cwd=tmp_path, capture_output=True, text=True, timeout=900, env=dict(os.environ, DSRT_LIB=DEVLIBM))
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        cam = dsrt.frame_camera(fr, 40.0, W, H, spp, depth)
+        gpu_ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
+        ours, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, math_mode=1))
         ref = _read_ppm(ref_out)
-        ours = np.frombuffer(open(our_out, "rb").read(), np.uint8).reshape(H, W, 3)
         lit = int((ref.max(axis=2) > 0).sum())
         assert lit > (0.08 * W * H if frame == 98 else 100), (frame, lit)
         differing = int((ref != ours).any(axis=2).sum())
         assert differing == 0, f"frame {frame}: {differing} of {W * H} pixels differ from the reference kernel's image ({lit} lit)"
 
 
-def test_the_product_build_differs_from_the_reference_kernel_only_statistically(tmp_path):
-    """The product (deterministic sin / cos / pow shared with the CPU oracle) against the reference kernel with the device math library: one differing ulp
+def test_math_mode_0_differs_from_the_reference_kernel_only_statistically(dsrt, gpu_ctx, tmp_path):
+    """The default mode (deterministic sin / cos / pow shared with the CPU oracle) against the reference kernel with the device math library: one differing ulp
     in cosf de-synchronises the rest of a pixel's random stream, so some pixels differ -- but the images are the same picture."""
     if not os.path.exists(REF_GPU):
         pytest.skip("oracle/_ref/ref_gpu not built")
     name = "station_near"
     ref = _reference_image(name, tmp_path).astype(np.int32)
-    ours = _our_image(name, tmp_path).astype(np.int32)
+    ours = _our_image(dsrt, gpu_ctx, name, 0).astype(np.int32)
     assert abs(float(ref.mean()) - float(ours.mean())) < 0.6                  # mean level within 0.6 / 255
     assert ((ref > 0).any(axis=2) == (ours > 0).any(axis=2)).mean() > 0.995  # the same pixels are lit
 
@@ -164,14 +146,13 @@ def test_a_contracted_build_of_the_reference_is_the_same_picture_not_the_same_by
     assert ((strict > 0).any(axis=2) == (fused > 0).any(axis=2)).mean() > 0.995
 
 
-def test_randomised_views_of_every_world_match_the_reference_kernel(tmp_path):
+def test_randomised_views_of_every_world_match_the_reference_kernel(dsrt, gpu_ctx, tmp_path):
     """A bounded fuzz of the executed pin: 30 random views over all six world files (spheres, lights with mixture sampling, metal, dielectric, textures, the
     3k-triangle station, the `quirks` mesh with its degenerate and duplicated faces), ragged image sizes, 1 to 24 samples, depths 1 to 50, cameras from inside
     the geometry to far outside, random un-normalised sun directions -- each rendered by the reference's own kernel (one ref_gpu process per view) and by this
-    kernel's device-libm build (one worker process for all), byte for byte."""
-    if not (os.path.exists(REF_GPU) and os.path.exists(DEVLIBM)):
-        pytest.skip("oracle/_ref/ref_gpu or libdsrt_hip_devlibm.so not built")
-    import json
+    library in math_mode 1, byte for byte."""
+    if not os.path.exists(REF_GPU):
+        pytest.skip("oracle/_ref/ref_gpu not built")
     rng = np.random.default_rng(20251005)
     worlds = ("c1_spheres", "lights", "station_3k", "textured", "mixed", "quirks")
     f32 = lambda v: float(np.float32(v))                      # noqa: E731 -- every number crosses both command lines as an exactly representable float
@@ -186,26 +167,8 @@ def test_randomised_views_of_every_world_match_the_reference_kernel(tmp_path):
         direction /= np.linalg.norm(direction)
         jobs.append({"trial": trial, "world": world, "W": W, "H": H, "spp": spp, "depth": depth, "from": [f32(v) for v in direction * dist + (0.0, 1.0, 0.0)],
                      "at": [f32(v) for v in rng.normal(size=3) * (0.0 if trial % 3 else 0.5)], "vfov": f32(rng.choice([20.0, 40.0, 75.0])),
-                     "sun": [f32(v) for v in rng.normal(size=3)], "out": str(tmp_path / f"ours_{trial}.rgb")})
-    (tmp_path / "jobs.json").write_text(json.dumps(jobs))
-    worker = (
-        "import sys, os, json\n"
-        "root, assets, jobs = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))\n"
-        "sys.path.insert(0, root)\n"
-        "import dsrt_amd as d\n"
-        "os.chdir(assets)\n"
-        "ctx, cache = d.Context(0), {}\n"
-        "for j in jobs:\n"
-        "    if j['world'] not in cache:\n"
-        "        hs = d.HostScene().add_world_file(j['world'] + '.world'); hs.build_bvh(); cache[j['world']] = hs\n"
-        "    hs = cache[j['world']]\n"
-        "    cam = d.camera_look_at(tuple(j['from']), tuple(j['at']), j['vfov'], j['W'], j['H'], j['spp'], j['depth'])\n"
-        "    ctx.upload(hs.view(cam, tuple(j['sun'])))\n"
-        "    rgb, _, _ = ctx.render_to_host(d.make_desc(j['W'], j['H'], j['spp'], j['depth']))\n"
-        "    open(j['out'], 'wb').write(rgb.tobytes())\n")
-    r = subprocess.run([sys.executable, "-c", worker, ROOT, ASSETS, str(tmp_path / "jobs.json")], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, DSRT_LIB=DEVLIBM))
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+                     "sun": [f32(v) for v in rng.normal(size=3)]})
+    cache = {}
     failures, lit_total = [], 0
     for j in jobs:
         ref_out = tmp_path / f"ref_{j['trial']}.ppm"
@@ -214,7 +177,11 @@ def test_randomised_views_of_every_world_match_the_reference_kernel(tmp_path):
         rr = subprocess.run([str(c) for c in cmd], cwd=ASSETS, capture_output=True, text=True, timeout=600)
         assert rr.returncode == 0, rr.stdout[-1500:] + rr.stderr[-1500:]
         ref = _read_ppm(ref_out)
-        ours = np.frombuffer(open(j["out"], "rb").read(), np.uint8).reshape(j["H"], j["W"], 3)
+        if j["world"] not in cache:
+            cache[j["world"]] = load_world(dsrt, j["world"])
+        cam = dsrt.camera_look_at(tuple(j["from"]), tuple(j["at"]), j["vfov"], j["W"], j["H"], j["spp"], j["depth"])
+        gpu_ctx.upload(cache[j["world"]].view(cam, tuple(j["sun"])))
+        ours, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(j["W"], j["H"], j["spp"], j["depth"], math_mode=1))
         lit_total += int((ref.max(axis=2) > 0).sum())
         bad = int((ref != ours).any(axis=2).sum())
         if bad:
