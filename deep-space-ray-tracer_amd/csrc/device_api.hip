@@ -973,6 +973,9 @@ static void gpu_render_scene_body(const GPUScene* scene, int width, int height) 
     d.gamma = scene->params.gamma;
     d.seed = scene->seed;
     d.rng_mode = scene->params.rng_mode == 1 ? 1 : 0;        // the reference always stores 0 here (src/gpu_scene_builder.cpp:577)
+    // The reference's entry point has nowhere to say which sinf / cosf / powf (DsrtRenderDesc.math_mode): the environment variable DSRT_MATH_MODE=1 asks this
+    // drop-in for the device math library's, i.e. for the very file the reference's own gpu_render_scene writes on this GPU (tests/test_gpu_reference_kernel.py)
+    { const char* e = std::getenv("DSRT_MATH_MODE"); d.math_mode = e && std::atoi(e) == 1 ? 1 : 0; }
     std::vector<uint8_t> fb((size_t)width * height * 3);
     if (dsrt_render_to_host(ctx, &d, fb.data(), nullptr, nullptr) != DSRT_OK) { std::fprintf(stderr, "render_kernel failed: %s\n", dsrt_last_error()); return; }
     if (dsrt_write_ppm("image_gpu.ppm", fb.data(), width, height) != DSRT_OK) std::fprintf(stderr, "Failed to open image_gpu.ppm for writing\n");

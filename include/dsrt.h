@@ -354,7 +354,9 @@ const char* dsrt_microbench_valu_kind_name(int kind);
 /* Drop-in layer: the reference's own three entry points.                                */
 /* ===================================================================================== */
 /* src/gpu_render.cu:1037-1038, declared at its call site src/main.cpp:24-25.  `scene` holds DEVICE pointers.
- * Blocking; writes image_gpu.ppm into the CWD; failures print to stderr and return (no file). */
+ * Blocking; writes image_gpu.ppm into the CWD; failures print to stderr and return (no file).  math_mode 0 unless the environment variable
+ * DSRT_MATH_MODE is 1 (the signature has no room for it): with it the file is, byte for byte, the one the reference's own gpu_render_scene
+ * writes when its source is built for this GPU. */
 void gpu_render_scene(const GPUScene* scene, int width, int height);
 
 /* C forms of build_gpu_scene / free_gpu_scene (inc/gpu_scene_builder.h:72-73): the C++ overloads taking

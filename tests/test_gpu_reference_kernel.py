@@ -188,3 +188,33 @@ def test_randomised_views_of_every_world_match_the_reference_kernel(dsrt, gpu_ct
             failures.append((j["trial"], j["world"], j["W"], j["H"], j["spp"], j["depth"], j["from"], bad))
     assert not failures, failures
     assert lit_total > 20000                                   # the views do see things
+
+
+def test_the_drop_in_gpu_render_scene_writes_the_reference_s_file(dsrt, tmp_path):
+    """The reference's three calls (src/main.cpp:405-428) through THIS library -- dsrt_build_gpu_scene, gpu_render_scene, dsrt_free_gpu_scene -- with DSRT_MATH_MODE=1,
+    against the same three calls of the reference's own code (ref_gpu): image_gpu.ppm, the whole file, header included."""
+    if not os.path.exists(REF_GPU):
+        pytest.skip("oracle/_ref/ref_gpu not built")
+    import ctypes as C
+    name = "mixed"
+    world, cam_args, spp = CASES[name]
+    (fx, fy, fz), (ax, ay, az), vfov, W, H, depth = cam_args
+    ref_out = tmp_path / "reference_image_gpu.ppm"
+    r = subprocess.run([str(c) for c in [REF_GPU, world + ".world", W, H, spp, depth, fx, fy, fz, ax, ay, az, vfov, *SUN, ref_out]], cwd=ASSETS, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    hs = load_world(dsrt, world)
+    cam = dsrt.camera_look_at(cam_args[0], cam_args[1], cam_args[2], W, H, spp, depth)
+    dev = dsrt.GPUScene()
+    assert dsrt.lib.dsrt_build_gpu_scene(hs._h, C.byref(cam), (C.c_float * 3)(*SUN), C.byref(dev)) == 0, dsrt.lib.dsrt_last_error()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    os.environ["DSRT_MATH_MODE"] = "1"
+    try:
+        dsrt.lib.gpu_render_scene(C.byref(dev), W, H)
+        ours = open("image_gpu.ppm", "rb").read()
+    finally:
+        os.environ.pop("DSRT_MATH_MODE", None)
+        os.chdir(cwd)
+        dsrt.lib.dsrt_free_gpu_scene(C.byref(dev))
+    assert ours == open(ref_out, "rb").read()
