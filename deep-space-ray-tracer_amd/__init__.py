@@ -74,6 +74,14 @@ class HostScene:
         self._built = False
         return self
 
+    def add_texture_file(self, path, flip_vertically=True):
+        """Texture slot of an image file (decoded into the scene's pool as the reference's builder decodes map_Kd files); the id a triangle added with
+        add_arrays carries in albedo_tex.  flip_vertically: the state of the reference's global stb flag (True once any MTL named a map)."""
+        slot = lib.dsrt_host_scene_add_texture_file(self._h, str(path).encode(), 1 if flip_vertically else 0)
+        if slot < 0:
+            _check(slot, "dsrt_host_scene_add_texture_file")
+        return slot
+
     def build_bvh(self, kind="median"):
         """kind "median": the reference's tree (parity); "sah": binned-SAH tree, "lbvh": linear BVH built on the GPU -- non-parity fast modes."""
         if kind == "median":

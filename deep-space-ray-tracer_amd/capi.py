@@ -104,7 +104,7 @@ assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.ite
 EXPORTS = [
     "dsrt_last_error", "dsrt_abi_version",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
-    "dsrt_host_scene_add_arrays", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
+    "dsrt_host_scene_add_arrays", "dsrt_host_scene_add_texture_file", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
     "dsrt_device_count", "dsrt_ctx_create", "dsrt_ctx_destroy", "dsrt_ctx_clone", "dsrt_ctx_device",
     "dsrt_multi_create", "dsrt_multi_destroy", "dsrt_multi_count", "dsrt_multi_uses_rccl", "dsrt_selftest_rccl_gather", "dsrt_multi_scene_upload", "dsrt_multi_render_frame", "dsrt_multi_render_sequence", "dsrt_scene_upload", "dsrt_scene_upload_device",
@@ -144,6 +144,7 @@ def load():
     sig("dsrt_host_scene_add_obj", C.c_int, [vp, C.c_char_p, C.c_double])
     sig("dsrt_host_scene_add_world_file", C.c_int, [vp, C.c_char_p])
     sig("dsrt_host_scene_add_arrays", C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int])
+    sig("dsrt_host_scene_add_texture_file", C.c_int, [vp, C.c_char_p, C.c_int])
     sig("dsrt_host_scene_build_bvh", C.c_int, [vp])
     sig("dsrt_host_scene_build_bvh_sah", C.c_int, [vp])
     sig("dsrt_host_scene_build_bvh_gpu", C.c_int, [vp, C.c_int, P(C.c_float), P(C.c_float)])

@@ -51,14 +51,14 @@ int material_slot(DsrtHostScene& hs, const std::shared_ptr<material>& m) {
     return slot;
 }
 
-int texture_slot(DsrtHostScene& hs, const std::string& path) {
+int texture_slot(DsrtHostScene& hs, const std::string& path, int flip = -1) {      // flip < 0: as the loader's latch says
     if (path.empty()) return -1;
     auto known = hs.tex_index.find(path);
     if (known != hs.tex_index.end()) return known->second;
     GPUTextureHeader h;
     h.offset = (int)hs.tex_pool.size();
     RgbImage img;
-    if (!load_rgb8(path, texture_flip_latch(), img)) {
+    if (!load_rgb8(path, flip < 0 ? texture_flip_latch() : flip != 0, img)) {
         std::fprintf(stderr, "WARN: failed to load texture '%s'\n", path.c_str());
         hs.tex_failed.push_back(path);
         h.width = h.height = 1;
@@ -230,6 +230,13 @@ int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int n
     for (int i = 0; i < num_spheres; ++i) { GPUSphere s = spheres[i]; s.material_id += base; hs->spheres.push_back(s); }
     hs->bvh_valid = false;
     return DSRT_OK;
+    });
+}
+
+int dsrt_host_scene_add_texture_file(DsrtHostScene* hs, const char* path, int flip_vertically) {
+    return dsrt::guarded("dsrt_host_scene_add_texture_file", [&]() -> int {
+    if (!hs || !path || !path[0]) { set_error("dsrt_host_scene_add_texture_file: bad argument"); return DSRT_ERR_INVALID; }
+    return texture_slot(*hs, path, flip_vertically != 0 ? 1 : 0);
     });
 }
 

@@ -34,9 +34,10 @@ extern "C" {
 const char* dsrt_last_error(void);
 /* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
  * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
- * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended).  dsrt_abi_version() returns the value the library was compiled with;
+ * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended;
+ * 6 = dsrt_host_scene_add_texture_file).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
-#define DSRT_ABI_VERSION 5
+#define DSRT_ABI_VERSION 6
 int dsrt_abi_version(void);
 
 /* ===================================================================================== */
@@ -63,6 +64,14 @@ int dsrt_host_scene_add_world_file(DsrtHostScene* hs, const char* world_path);
  * scene's material table. */
 int dsrt_host_scene_add_arrays(DsrtHostScene* hs, const GPUTriangle* tris, int num_tris, const GPUSphere* spheres,
                                int num_spheres, const GPUMaterial* mats, int num_mats);
+
+/* Decode an image file into the scene's texture pool the way the reference's builder does (HostTextureRegistry::get_or_load,
+ * src/gpu_scene_builder.cpp:205-246: forced RGB, powf(c / 255, 2.2) per channel, one slot per distinct path, a file that cannot be
+ * decoded becomes one white texel and is listed by dsrt_host_scene_texture_failures) and return its slot: the value a GPUTriangle's
+ * albedo_tex must carry when triangles are added with dsrt_host_scene_add_arrays.  `flip_vertically` is the state of the reference's
+ * global stb flag at that moment (image_texture::load sets it, inc/texture.h:133; SURVEY.md note T): 1 for any scene whose MTL named a map.
+ * Returns the slot (>= 0) or a negative DSRT_ERR_*. */
+int dsrt_host_scene_add_texture_file(DsrtHostScene* hs, const char* path, int flip_vertically);
 
 /* Median-split BVH over all triangles added so far: leaf <= 4, std::nth_element on the centroid along
  * the widest centroid axis, pre-order node numbering (src/gpu_scene_builder.cpp:343-459). */

@@ -90,6 +90,31 @@ def test_flatten_and_bvh_match_reference_builder(dsrt, name):
         assert got[key].tobytes() == ref[key].tobytes(), f"{name}: {key} differs from the reference builder"
 
 
+def test_a_scene_handed_over_as_arrays_with_texture_files_is_the_scene_the_loader_builds(dsrt):
+    """What integration/reference_entry_points.cpp does behind the reference's build_gpu_scene: the host owns the flattening (there, the reference's own
+    classes) and hands over reference-layout arrays plus texture FILES (dsrt_host_scene_add_texture_file); tree, texture table and pool must come out as
+    they do when this library's loader reads the same OBJ -- which test_flatten_and_bvh_match_reference_builder ties to the reference's builder."""
+    whole = dsrt.HostScene().add_obj(os.path.join(ASSETS, "textured.obj"))
+    want = whole.arrays()
+    maps = ["checker.ppm", "stripes.png", "does_not_exist.png"]                          # in the order the triangles first name them
+    again = dsrt.HostScene()
+    slots = [again.add_texture_file(os.path.join(ASSETS, m)) for m in maps]
+    assert slots == [0, 1, 2] and again.add_texture_file(os.path.join(ASSETS, "stripes.png")) == 1      # one slot per distinct path
+    assert sorted(set(int(t) for t in want["tris"]["albedo_tex"])) == [-1, 0, 1, 2]
+    again.add_arrays(tris=want["tris"], mats=want["mats"])
+    got = again.arrays()
+    for key in ("tris", "mats", "idx", "nodes", "texhdr", "texpool"):
+        assert got[key].tobytes() == want[key].tobytes(), key
+    assert [os.path.basename(p) for p in again.texture_failures] == ["does_not_exist.png"]
+    upright = dsrt.HostScene()
+    upright.add_texture_file(os.path.join(ASSETS, "checker.ppm"), flip_vertically=False)
+    w, h = int(want["texhdr"][0]["width"]), int(want["texhdr"][0]["height"])
+    a = upright.arrays()["texpool"].reshape(h, w, 3)
+    assert np.array_equal(a[::-1], want["texpool"][: w * h * 3].reshape(h, w, 3)) and not np.array_equal(a, a[::-1])
+    with pytest.raises(Exception):
+        dsrt.HostScene().add_texture_file("")
+
+
 def test_big_leaf_and_stack_need(dsrt):
     hs = load_world(dsrt, "quirks")
     nodes = hs.arrays()["nodes"]
