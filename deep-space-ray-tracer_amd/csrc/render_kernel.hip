@@ -212,23 +212,33 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const float tl = fmaxf(fmaxf(kTMin, t0xl), fmaxf(t0yl, t0zl)), tr = fmaxf(fmaxf(kTMin, t0xr), fmaxf(t0yr, t0zr));
                         const bool hl = !(fminf(fminf(closest, t1xl), fminf(t1yl, t1zl)) <= tl);
                         const bool hr = !(fminf(fminf(closest, t1xr), fminf(t1yr, t1zr)) <= tr);
-                        // nearer child by box centre along the ray :433-453 (only matters when both are hit)
-                        const v2f dc = (((lox + hix) * 0.5f - ro.x) * rd.x + ((loy + hiy) * 0.5f - ro.y) * rd.y) + ((loz + hiz) * 0.5f - ro.z) * rd.z;
+                        // nearer child by box centre along the ray :433-453 (only matters when both are hit).  The reference compares
+                        //   d = ((c.x - o.x) * dir.x + (c.y - o.y) * dir.y) + (c.z - o.z) * dir.z,   c = 0.5f * (lo + hi)
+                        // of the two children.  Computed here is 2 d, with the reference's roundings: s = lo + hi is the reference's sum; the product
+                        // by 0.5f is exact, and fma(-2, o, s) = fl(s - 2 o) = 2 fl(0.5 s - o), because scaling by two commutes with rounding; so do the
+                        // products and sums that follow.  dL < dR <=> 2 dL < 2 dR, and three packed multiplications per visit are gone.  (The
+                        // identity needs the reference's intermediates to be zero or normal numbers below 1.7e38: coordinates in metres are.)
+                        const v2f m2 = {-2.0f, -2.0f}, ox2 = {ro.x, ro.x}, oy2 = {ro.y, ro.y}, oz2 = {ro.z, ro.z};
+                        const v2f ux = __builtin_elementwise_fma(m2, ox2, lox + hix), uy = __builtin_elementwise_fma(m2, oy2, loy + hiy), uz = __builtin_elementwise_fma(m2, oz2, loz + hiz);
+                        const v2f dc = (ux * rd.x + uy * rd.y) + uz * rd.z;
                         const bool left_near = dc.x < dc.y;
                         const bool both = hl && hr;
                         // the far child goes to stack[sp]; written unconditionally (slot sp is above the top, slot K is a dump
                         // slot for sp >= K), the stack only grows when both children were hit
-                        lds_stack[wave][sp < K ? sp : K][lane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
+                        const uint2 far = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
+                        lds_stack[wave][sp < K ? sp : K][lane] = far;
                         if (wave_any(sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store
                             if (sp - K < args.spill_entries) {
-                                args.spill[(size_t)(sp - K) * args.spill_stride + glane] = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
+                                args.spill[(size_t)(sp - K) * args.spill_stride + glane] = far;
                                 if (COUNT) c[C_STACK_SPILLS]++;
                             } else flags |= kFlagStackOverflow;
                         }
                         sp += both ? 1 : 0;
                         if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
-                        const int near_ref = left_near ? ref_l : ref_r;
-                        cur = both ? near_ref : (hl ? ref_l : (hr ? ref_r : kRefPop));
+                        // next node, without branches: the left child if both were hit and it is the nearer one, or if it alone was hit
+                        const bool take_left = hl && (left_near || !hr);            // (written as mask logic: a select between two predicates compiles to five VALU instructions)
+                        const int child = take_left ? ref_l : ref_r;
+                        cur = (hl || hr) ? child : kRefPop;
                     }
                 }
             }
