@@ -215,6 +215,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         v.stack_need = stack_need;
 
         if (isect.size() / 5 > (size_t)(1 << 28)) { set_error("too many triangle pair records"); return DSRT_ERR_INVALID; }
+        if (pairs.size() / 4 >= ((size_t)1 << 26)) { set_error("more than 2^26 internal BVH nodes (the kernel addresses node records by a 32-bit byte offset)"); return DSRT_ERR_INVALID; }
     }
     mats.resize((size_t)h.num_materials * 3);
     for (int i = 0; i < h.num_materials; ++i) {

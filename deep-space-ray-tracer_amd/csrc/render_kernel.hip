@@ -165,18 +165,22 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 
             // ---------------- phase I: pops and internal nodes ----------------
             for (;;) {
-                const int n_desc = __popcll(wave_ballot((unsigned)cur < (unsigned)kRefNone));      // kRefPop or an internal node
+                const bool descending = (unsigned)cur < (unsigned)kRefNone;                          // kRefPop or an internal node
+                const int n_desc = __popcll(wave_ballot(descending));
                 const int n_leaf = __popcll(wave_ballot(cur < 0));
                 if (n_desc == 0 || leaf_waste * 10 >= n_desc * args.leaf_ratio4) break;
                 leaf_waste += n_leaf;
                 wait_waste += n_wait;
-                if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
+                if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST || (cur == kRefNone && state <= ST_TRAV_SHADOW)) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
                 // bbox_hit(node, ray, t_min, closest) for a box already known to be hit (src/gpu_render.cu:422-424, 462-468)
-                if (cur == kRefPop) {
-                    if (sp == 0) { cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE); }
-                    else {
+                {
+                    const bool popping = cur == kRefPop;
+                    const bool finished = popping && sp == 0;
+                    // a ray that has emptied its stack: its state leaves ST_TRAV_* when the node loop is left (below), not here, every iteration
+                    if (finished) cur = kRefNone;
+                    if (popping != finished) {                 // popping with something on the stack (one compare of sp, not two)
                         --sp;
                         uint2 e = lds_stack[wave][sp < K ? sp : K][lane];
                         if (wave_any(sp >= K)) {               // wave-uniform guard: keeps the common path a plain ds_read_b64
@@ -192,7 +196,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         flags |= cur >= S.num_pairs ? kFlagBadNodeRef : kFlagStepCap;
                         cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE);
                     } else {
-                        const float4* rec = S.pairs + (size_t)cur * 4;
+                        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.pairs) + ((uint32_t)cur << 6));     // 32-bit offset from a scalar base (num_pairs < 2^26, checked at upload)
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                         const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
                         if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; const int dpt = __float_as_int(q3.z); if (dpt < 6) c[C_VISITS_LT6]++; if (dpt < 9) c[C_VISITS_LT9]++; if (dpt < 12) c[C_VISITS_LT12]++; }
@@ -227,7 +231,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         // slot for sp >= K), the stack only grows when both children were hit
                         const uint2 far = make_uint2((uint32_t)(left_near ? ref_r : ref_l), __float_as_uint(left_near ? tr : tl));
                         lds_stack[wave][sp < K ? sp : K][lane] = far;
-                        if (wave_any(sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store
+                        if (wave_any(sp >= K)) if (both && sp >= K) {      // wave-uniform guard around the rare spill store (one vote per site: a shared one at the top of the iteration was 1 % slower)
                             if (sp - K < args.spill_entries) {
                                 args.spill[(size_t)(sp - K) * args.spill_stride + glane] = far;
                                 if (COUNT) c[C_STACK_SPILLS]++;
@@ -236,12 +240,15 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         sp += both ? 1 : 0;
                         if (COUNT && (uint32_t)sp > c[C_MAX_STACK]) c[C_MAX_STACK] = (uint32_t)sp;
                         // next node, without branches: the left child if both were hit and it is the nearer one, or if it alone was hit
-                        const bool take_left = hl && (left_near || !hr);            // (written as mask logic: a select between two predicates compiles to five VALU instructions)
+                        const bool take_left = hl && !(hr && !left_near);            // (written as mask logic: a select between two predicates compiles to five VALU instructions)
                         const int child = take_left ? ref_l : ref_r;
                         cur = (hl || hr) ? child : kRefPop;
                     }
                 }
             }
+
+            // rays that emptied their stack in the node loop: TRAV_CLOSEST -> SHADE, TRAV_SHADOW -> SHADOW_DONE (a lane in ST_TRAV_* without a node has just ended)
+            if (cur == kRefNone && state >= ST_TRAV_CLOSEST && state <= ST_TRAV_SHADOW) state -= (ST_TRAV_CLOSEST - ST_SHADE);
 
             // ---------------- phase L: every lane parked at a leaf intersects it, triangle by triangle :413-420 ----------------
             const bool at_leaf = cur < 0;
