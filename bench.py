@@ -57,7 +57,7 @@ VALU_PEAK_CYCLES_PER_WAVE_INSTR = 2.0   # /opt/skills/guides/MI355X_MICROARCH.md
 # VALU instruction classes of the production kernel's three hot loops: static counts (tools/isa_mix.py --loops on this build) weighted by the loops'
 # shares of the issued stream, node loop 0.57 / leaf pass 0.21 / advance 0.22 (trip counts of the counting build x VALU per trip against SQ_INSTS_VALU;
 # profiles/r03/isa_mix.txt): share of simple-rate, half-rate and quarter-rate instructions
-KERNEL_VALU_CLASS_SHARES = {"simple": 0.27, "half": 0.66, "quarter": 0.07}
+KERNEL_VALU_CLASS_SHARES = {"simple": 0.26, "half": 0.67, "quarter": 0.07}
 RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0>"
 
 
@@ -903,8 +903,8 @@ def main():
                                           "(GRBM_GUI_ACTIVE / 8 / kernel time); the best this device was measured to do is issue_costs['v_add_f32'] cycles (simple ops), and "
                                           "most of this kernel's instructions are of the classes that cost twice that -- see mix")
                     roof["instructions_per_sample"] = pmc["SQ_INSTS_VALU"] / float(W * H * spp)       # wave-instructions per sample: the figure optimisation lowers while
-                    roof["frac_reading"] = ("frac is an issue RATE: a change that renders the frame with fewer instructions (round 3's leaf dealing: 241.7 -> 231.5 wave-"   # frac stands still
-                                            "instructions per sample) raises Msamples/s, lane occupancy and useful_lane_frac, not frac")
+                    roof["frac_reading"] = ("frac is an issue RATE: a change that renders the frame with fewer instructions (round 3: leaf dealing 241.7 -> 231.5 wave-"   # frac stands still
+                                            "instructions per sample, the trimmed node visit -> 219) raises Msamples/s, not frac")
                     roof["valu_lane_occupancy"] = pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * pmc.get("SQ_ACTIVE_INST_VALU", 1.0))
                     roof["useful_lane_frac"] = roof["frac"] * roof["valu_lane_occupancy"]
                     roof["shader_clock_GHz"] = clk / 1e9
