@@ -191,7 +191,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         shade.reserve(((size_t)N + (size_t)M / 2 + 2) * 3);
         auto ref_of = [&](int node) -> int {
             const GPUBVHNode& n = h.bvh_nodes[node];
-            if (n.tri_count <= 0) return slot_of[node];
+            if (n.tri_count <= 0) return slot_of[node] + kRefBias;
             const int first_pair = emit_leaf(n);
             if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, first_pair);
             big.push_back(make_int2(first_pair, n.tri_count));
@@ -215,7 +215,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         v.stack_need = stack_need;
 
         if (isect.size() / 5 > (size_t)(1 << 28)) { set_error("too many triangle pair records"); return DSRT_ERR_INVALID; }
-        if (pairs.size() / 4 >= ((size_t)1 << 26)) { set_error("more than 2^26 internal BVH nodes (the kernel addresses node records by a 32-bit byte offset)"); return DSRT_ERR_INVALID; }
+        if (pairs.size() / 4 + kRefBias >= ((size_t)1 << 26)) { set_error("more than 2^26 - 64 internal BVH nodes (the kernel addresses node records by a 32-bit byte offset)"); return DSRT_ERR_INVALID; }
     }
     mats.resize((size_t)h.num_materials * 3);
     for (int i = 0; i < h.num_materials; ++i) {
@@ -247,7 +247,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
     } else { out.tex_headers.reset(); out.tex_pool.reset(); }
 
-    v.pairs = out.pairs.p; v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
+    v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
     v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
     v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
     v.num_pairs = (int)(pairs.size() / 4); v.num_tri_pairs = (int)(isect.size() / 5); v.num_big_leaves = (int)big.size();

@@ -12,7 +12,7 @@
 //                q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x)   q1 = (L.lo.y, R.lo.y, L.hi.y, R.hi.y)
 //                q2 = (L.lo.z, R.lo.z, L.hi.z, R.hi.z)   q3 = (left_ref, right_ref, depth, -) as int bits
 //              Records are in depth-first order (a left child sits right behind its parent).
-//   child ref  >= 0: index of an internal node in `pairs`
+//   child ref  >= kRefBias (64): index + kRefBias of an internal node in `pairs` (below)
 //              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles whose first PAIR record is
 //                    `payload`; code 7: payload indexes `big_leaves` {first pair, count} (leaves of more than 7 triangles
 //                    only arise from coincident centroids, builder :408-414).
@@ -38,16 +38,25 @@
 namespace dsrt {
 
 constexpr int kLeafBit = (int)0x80000000u;
-constexpr int kRefNone = 0x7FFFFFFF;           // "no node": traversal finished / no BVH
-constexpr int kRefPop = 0x7FFFFFFE;            // "take the next postponed child from the stack"
+// Node references as a lane's `cur` holds them.  Every sentinel and every class boundary is an INLINE constant of the ISA (integers -16 .. 64 cost no
+// register and no literal): the traversal loop's compares and selects name them directly, where 0x7FFFFFFE cost a move per iteration and a register.
+//   cur <  0            a leaf (bit 31 | code << 28 | payload)
+//   cur == kRefNone     no node: traversal finished / no BVH
+//   cur == kRefPop      take the next postponed child from the stack
+//   cur >= kRefBias     internal node number (cur - kRefBias) of `pairs`
+constexpr int kRefNone = 62;
+constexpr int kRefPop = 63;
+constexpr int kRefBias = 64;
 
 __host__ __device__ inline bool ref_is_leaf(int r) { return r < 0; }
+__host__ __device__ inline bool ref_is_internal(int r) { return r >= kRefBias; }
 __host__ __device__ inline int leaf_code(int r) { return (r >> 28) & 7; }
 __host__ __device__ inline int leaf_payload(int r) { return r & 0x0FFFFFFF; }
 inline int make_leaf_ref(int code, int payload) { return kLeafBit | (code << 28) | payload; }
 
 struct DeviceScene {
     const float4* pairs;
+    const char*   pairs_biased; // pairs - kRefBias records, as bytes: an internal reference r is the record at pairs_biased + (r << 6)
     const float4* tri_pairs;
     const float4* tri_shade;
     const float4* tri_uv;

@@ -148,7 +148,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
         // that reached a leaf PARK there until enough lanes are parked, then all parked leaves are intersected together,
         // one triangle index at a time.  Each lane still performs exactly the reference's sequence of box tests,
         // triangle tests and pops -- only WHEN a lane runs changes, never what it does.
-        //   cur >= 0 (< kRefPop): internal node to visit   cur == kRefPop: take the next postponed child
+        //   cur >= kRefBias: internal node to visit          cur == kRefPop: take the next postponed child
         //   cur <  0            : parked at a leaf          cur == kRefNone: no ray
         // =====================================================================================
         // Leaving a phase is decided by accumulated waste, in lane-slots: every wave iteration spent here costs the lanes
@@ -165,7 +165,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 
             // ---------------- phase I: pops and internal nodes ----------------
             for (;;) {
-                const bool descending = (unsigned)cur < (unsigned)kRefNone;                          // kRefPop or an internal node
+                const bool descending = cur > kRefNone;                                              // kRefPop or an internal node
                 const int n_desc = __popcll(wave_ballot(descending));
                 const int n_leaf = __popcll(wave_ballot(cur < 0));
                 if (n_desc == 0 || leaf_waste * 10 >= n_desc * args.leaf_ratio4) break;
@@ -191,12 +191,12 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                 }
 
                 // node visit: both child boxes from one 64-byte record
-                if ((unsigned)cur < (unsigned)kRefPop) {
-                    if (CHECKED && (cur >= S.num_pairs || ++steps > kStepCap)) {
-                        flags |= cur >= S.num_pairs ? kFlagBadNodeRef : kFlagStepCap;
+                if (cur > kRefPop) {
+                    if (CHECKED && (cur - kRefBias >= S.num_pairs || ++steps > kStepCap)) {
+                        flags |= cur - kRefBias >= S.num_pairs ? kFlagBadNodeRef : kFlagStepCap;
                         cur = kRefNone; state -= (ST_TRAV_CLOSEST - ST_SHADE);
                     } else {
-                        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.pairs) + ((uint32_t)cur << 6));     // 32-bit offset from a scalar base (num_pairs < 2^26, checked at upload)
+                        const float4* rec = reinterpret_cast<const float4*>(S.pairs_biased + ((uint32_t)cur << 6));     // 32-bit offset from a scalar base (num_pairs < 2^26 - 64, checked at upload)
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                         const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
                         if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; const int dpt = __float_as_int(q3.z); if (dpt < 6) c[C_VISITS_LT6]++; if (dpt < 9) c[C_VISITS_LT9]++; if (dpt < 12) c[C_VISITS_LT12]++; }
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) dsrt_tile_cost_kernel(const DeviceScene S
             int sp = 0, cur = S.root_ref;
             for (int guard = 0; guard < (1 << 20) && !hit; ++guard) {
                 if (cur >= 0) {
-                    const float4* rec = S.pairs + (size_t)cur * 4;
+                    const float4* rec = S.pairs + (size_t)(cur - kRefBias) * 4;
                     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                     float tl, tr;
                     const bool hl = slab(mk(q0.x, q1.x, q2.x), mk(q0.z, q1.z, q2.z), ro, rinv, kTMax, tl);
