@@ -300,10 +300,10 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const F3 lrd = mk(__int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.y))),
                                           __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(rd.z))));
                         const int lpair = __builtin_amdgcn_ds_bpermute(src4, first) + (helping ? 1 : 0);
-                        v2f t = {0.0f, 0.0f}, u = {0.0f, 0.0f}, v = {0.0f, 0.0f};
+                        v2f t, u, v;                                         // meaningful only where `ok` says so (unset elsewhere: six moves per pass)
                         int ok = 0;                                          // bit 0: A passed every test but the one against `closest`, bit 1: B
                         if (COUNT) c[C_TRI_SLOTS] += 2;
-                        if ((at_leaf && count > 0) || helping) {
+                        if (count > 0 || helping) {                          // (count is 0 in the lanes that are not at a leaf: two plain compares, not a select between predicates)
                             bool ok_a, ok_b;
                             moller_trumbore_pair(S.tri_pairs + (size_t)lpair * 5, lro, lrd, t, u, v, ok_a, ok_b);
                             ok = (ok_a ? 1 : 0) | (ok_b ? 2 : 0);
