@@ -95,6 +95,7 @@ struct DevBuf {
 // The scene in traversal layout, owning its device memory.
 struct PackedScene {
     DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, materials;
+    DevBuf<uint8_t> pair_depth;
     DevBuf<int2> big_leaves;
     DevBuf<GPUSphere> spheres;
     DevBuf<GPUTextureHeader> tex_headers;
@@ -123,6 +124,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
     for (int i = 0; i < h.num_spheres; ++i) if (h.spheres[i].material_id < 0 || h.spheres[i].material_id >= h.num_materials) { set_error("sphere material id out of range"); return DSRT_ERR_INVALID; }
 
     std::vector<float4> pairs, isect, shade, uv, mats;
+    std::vector<int> depth_of_all;                                       // depth of every record of `pairs` (the counting build's histogram reads it)
     std::vector<int2> big;
     DeviceScene& v = out.view;
     std::memset(&v, 0, sizeof v);
@@ -206,8 +208,9 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
             pairs[4 * s + 1] = as_f4(l.bbox_min.y, r.bbox_min.y, l.bbox_max.y, r.bbox_max.y);
             pairs[4 * s + 2] = as_f4(l.bbox_min.z, r.bbox_min.z, l.bbox_max.z, r.bbox_max.z);
             const int ref_left = ref_of(n.left), ref_right = ref_of(n.right);          // in this order: leaf records follow the walk
-            pairs[4 * s + 3] = as_f4(bits(ref_left), bits(ref_right), bits(depth_of[s]), 0.0f);
+            pairs[4 * s + 3] = as_f4(bits(ref_left), bits(ref_right), l.bbox_min.x + l.bbox_max.x, r.bbox_min.x + r.bbox_max.x);   // the x sums of the ordering test, in float as the kernel would form them
         }
+        depth_of_all = depth_of;
         const GPUBVHNode& root = h.bvh_nodes[0];
         v.root_lo[0] = root.bbox_min.x; v.root_lo[1] = root.bbox_min.y; v.root_lo[2] = root.bbox_min.z;
         v.root_hi[0] = root.bbox_max.x; v.root_hi[1] = root.bbox_max.y; v.root_hi[2] = root.bbox_max.z;
@@ -237,6 +240,11 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
     }
 
     int rc;
+    {
+        std::vector<uint8_t> depth_bytes(pairs.size() / 4);
+        for (size_t i = 0; i < depth_bytes.size(); ++i) depth_bytes[i] = (uint8_t)depth_of_all[i];
+        if ((rc = out.pair_depth.upload(depth_bytes))) return rc;
+    }
     if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_pairs.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
         (rc = out.tri_uv.upload(uv)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
     std::vector<GPUSphere> sph(h.spheres, h.spheres + h.num_spheres);
@@ -247,7 +255,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
     } else { out.tex_headers.reset(); out.tex_pool.reset(); }
 
-    v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
+    v.pair_depth = out.pair_depth.p; v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
     v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
     v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
     v.num_pairs = (int)(pairs.size() / 4); v.num_tri_pairs = (int)(isect.size() / 5); v.num_big_leaves = (int)big.size();

@@ -10,7 +10,8 @@
 //              interleaved so that every (left, right) pair of like coordinates sits in adjacent registers after the load
 //              and the slab arithmetic runs on packed fp32 instructions:
 //                q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x)   q1 = (L.lo.y, R.lo.y, L.hi.y, R.hi.y)
-//                q2 = (L.lo.z, R.lo.z, L.hi.z, R.hi.z)   q3 = (left_ref, right_ref, depth, -) as int bits
+//                q2 = (L.lo.z, R.lo.z, L.hi.z, R.hi.z)   q3 = (left_ref, right_ref as int bits, L.lo.x + L.hi.x, R.lo.x + R.hi.x)
+//              (the last two: the x sums of the child-ordering test, formed in float on the host exactly as the kernel would -- one packed add per visit)
 //              Records are in depth-first order (a left child sits right behind its parent).
 //   child ref  >= kRefBias (64): index + kRefBias of an internal node in `pairs` (below)
 //              <  0: a leaf: bit31 | code<<28 | payload.  code 0..6: count = code+1 triangles whose first PAIR record is
@@ -56,6 +57,7 @@ inline int make_leaf_ref(int code, int payload) { return kLeafBit | (code << 28)
 
 struct DeviceScene {
     const float4* pairs;
+    const uint8_t* pair_depth;  // depth of every record of `pairs` (root 0): read by the counting build only
     const char*   pairs_biased; // pairs - kRefBias records, as bytes: an internal reference r is the record at pairs_biased + (r << 6)
     const float4* tri_pairs;
     const float4* tri_shade;

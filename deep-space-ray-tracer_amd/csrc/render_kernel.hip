@@ -199,7 +199,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const float4* rec = reinterpret_cast<const float4*>(S.pairs_biased + ((uint32_t)cur << 6));     // 32-bit offset from a scalar base (num_pairs < 2^26 - 64, checked at upload)
                         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                         const int ref_l = __float_as_int(q3.x), ref_r = __float_as_int(q3.y);
-                        if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; const int dpt = __float_as_int(q3.z); if (dpt < 6) c[C_VISITS_LT6]++; if (dpt < 9) c[C_VISITS_LT9]++; if (dpt < 12) c[C_VISITS_LT12]++; }
+                        if (COUNT) { c[C_NODES_ENTERED]++; c[C_INTERNAL_ENTERED]++; c[C_BOX_FETCHES] += 2; const int dpt = S.pair_depth[cur - kRefBias]; if (dpt < 6) c[C_VISITS_LT6]++; if (dpt < 9) c[C_VISITS_LT9]++; if (dpt < 12) c[C_VISITS_LT12]++; }
                         // Both boxes at once: every quantity below is a (left, right) pair in two adjacent registers, so the
                         // subtractions / multiplications are packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32: IEEE per component,
                         // same results as the scalar forms).  Record layout: q0 = (L.lo.x, R.lo.x, L.hi.x, R.hi.x), q1 = y, q2 = z.
@@ -218,12 +218,12 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const bool hr = !(fminf(fminf(closest, t1xr), fminf(t1yr, t1zr)) <= tr);
                         // nearer child by box centre along the ray :433-453 (only matters when both are hit).  The reference compares
                         //   d = ((c.x - o.x) * dir.x + (c.y - o.y) * dir.y) + (c.z - o.z) * dir.z,   c = 0.5f * (lo + hi)
-                        // of the two children.  Computed here is 2 d, with the reference's roundings: s = lo + hi is the reference's sum; the product
+                        // of the two children.  Computed here is 2 d, with the reference's roundings: s = lo + hi is the reference's sum (the x sums come with the record); the product
                         // by 0.5f is exact, and fma(-2, o, s) = fl(s - 2 o) = 2 fl(0.5 s - o), because scaling by two commutes with rounding; so do the
                         // products and sums that follow.  dL < dR <=> 2 dL < 2 dR, and three packed multiplications per visit are gone.  (The
                         // identity needs the reference's intermediates to be zero or normal numbers below 1.7e38: coordinates in metres are.)
                         const v2f m2 = {-2.0f, -2.0f}, ox2 = {ro.x, ro.x}, oy2 = {ro.y, ro.y}, oz2 = {ro.z, ro.z};
-                        const v2f ux = __builtin_elementwise_fma(m2, ox2, lox + hix), uy = __builtin_elementwise_fma(m2, oy2, loy + hiy), uz = __builtin_elementwise_fma(m2, oz2, loz + hiz);
+                        const v2f ux = __builtin_elementwise_fma(m2, ox2, (v2f){q3.z, q3.w}), uy = __builtin_elementwise_fma(m2, oy2, loy + hiy), uz = __builtin_elementwise_fma(m2, oz2, loz + hiz);
                         const v2f dc = (ux * rd.x + uy * rd.y) + uz * rd.z;
                         const bool left_near = dc.x < dc.y;
                         const bool both = hl && hr;
