@@ -86,6 +86,11 @@ __device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2
     return stop;
 }
 
+#ifndef DSRT_NODE_UNROLL
+#define DSRT_NODE_UNROLL 2
+#endif
+constexpr int kNodeUnroll = DSRT_NODE_UNROLL;
+
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
@@ -169,8 +174,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                 const int n_desc = __popcll(wave_ballot(descending));
                 const int n_leaf = __popcll(wave_ballot(cur < 0));
                 if (n_desc == 0 || leaf_waste * 10 >= n_desc * args.leaf_ratio4) break;
-                leaf_waste += n_leaf;
-                wait_waste += n_wait;
+                // Two iterations per look at the votes: the loop's own bookkeeping (two compares, seven scalar instructions, two branches) is paid every other time.
+                leaf_waste += kNodeUnroll * n_leaf;
+                wait_waste += kNodeUnroll * n_wait;
+#pragma unroll
+                for (int rep = 0; rep < kNodeUnroll; ++rep) {
                 if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST || (cur == kRefNone && state <= ST_TRAV_SHADOW)) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
@@ -244,6 +252,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const int child = take_left ? ref_l : ref_r;
                         cur = (hl || hr) ? child : kRefPop;
                     }
+                }
                 }
             }
 
