@@ -86,10 +86,8 @@ __device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2
     return stop;
 }
 
-#ifndef DSRT_NODE_UNROLL
-#define DSRT_NODE_UNROLL 2
-#endif
-constexpr int kNodeUnroll = DSRT_NODE_UNROLL;
+// Node-loop iterations per look at the loop's votes (1: +1.4 % time, 3: no better than 2; profiles/r03/ab_node_loop_unroll.jsonl).
+constexpr int kNodeUnroll = 2;
 
 template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
@@ -178,7 +176,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                 leaf_waste += kNodeUnroll * n_leaf;
                 wait_waste += kNodeUnroll * n_wait;
 #pragma unroll
-                for (int rep = 0; rep < kNodeUnroll; ++rep) {
+                for (int rep = 0; rep < kNodeUnroll; ++rep) {           // (body not re-indented: it is the iteration described above)
                 if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST || (cur == kRefNone && state <= ST_TRAV_SHADOW)) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
@@ -253,7 +251,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         cur = (hl || hr) ? child : kRefPop;
                     }
                 }
-                }
+                }                                                       // rep
             }
 
             // rays that emptied their stack in the node loop: TRAV_CLOSEST -> SHADE, TRAV_SHADOW -> SHADOW_DONE (a lane in ST_TRAV_* without a node has just ended)
