@@ -991,3 +991,25 @@ def test_device_material_helpers_match_the_reference_known_answers(dsrt, gpu_ctx
     a, b = dev.dielectric(d, nn, front, ref_idx, state), orc.dielectric(d, nn, front, ref_idx, state)
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
     assert 16 < (b[1] != state).sum() < n                                     # both the drawing and the non-drawing branch occur
+
+
+@pytest.mark.parametrize("scale", [1.0 / 64.0, 4096.0, 1.0e9])
+def test_scaled_scenes_match_the_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, scale):
+    """The node visit orders its two children by 2 d instead of the reference's d (fma(-2, o, lo + hi) = 2 (0.5 (lo + hi) - o), render_kernel.hip): an identity
+    of IEEE arithmetic as long as no intermediate is subnormal or overflows.  The station at 1/64 of its size, 4096 times and a billion times its size (coordinates
+    up to 5e10, products up to 1e22), camera moved with it: image bits and every work counter -- which depend on the ORDER in which children are visited -- equal the
+    oracle's, which computes d the reference's way."""
+    from conftest import ASSETS
+    hs = dsrt.HostScene().add_obj(os.path.join(ASSETS, "station_3k.obj"), scale=scale)
+    hs.build_bvh()
+    W, H, spp, depth = 160, 90, 8, 50
+    cam = dsrt.camera_look_at(tuple(c * scale for c in (12.0, 9.0, 38.0)), (0.0, 0.0, 0.0), 40.0, W, H, spp, depth)
+    scene = hs.view(cam, SUN)
+    want_rgb, want_f32, want_cnt = oracle.render(scene, W, H)
+    gpu_ctx.upload(scene)
+    rgb, f32, st = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=2), want_f32=True)
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32))
+    for key in ("rays", "box_fetches", "nodes_entered", "internal_entered", "tri_tests", "hit_updates", "max_stack"):
+        assert getattr(st, key) == want_cnt[key], (key, getattr(st, key), want_cnt[key])
+    if scale >= 1.0:
+        assert int((rgb.max(axis=2) > 0).sum()) > 0.02 * W * H       # (at 1/64 the reference's absolute epsilons -- t_min 1e-3, |det| 1e-8 -- eat most hits: compared all the same)
