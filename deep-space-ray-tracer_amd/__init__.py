@@ -208,6 +208,13 @@ def selftest_rccl_gather(device=0, nbytes=1 << 20):
     _check(lib.dsrt_selftest_rccl_gather(int(device), int(nbytes)), "dsrt_selftest_rccl_gather")
 
 
+def microbench_copy(nbytes=2 << 30, blocks_per_cu=8, reps=8, device=0):
+    """HBM streaming-copy calibration (include/dsrt.h): float4 grid-stride copy; GB/s counts bytes read + written."""
+    ms, moved = C.c_float(), C.c_double()
+    _check(lib.dsrt_microbench_copy(int(device), int(nbytes), int(blocks_per_cu), int(reps), C.byref(ms), C.byref(moved)), "dsrt_microbench_copy")
+    return {"bytes_per_buffer": int(nbytes), "blocks_per_cu": blocks_per_cu, "reps": reps, "ms": ms.value, "GBps": moved.value / ms.value / 1e6}
+
+
 def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_bytes=19 << 20, iters=2000, device=0):
     """Gather-rate calibration kernel (include/dsrt.h): returns {"ms", "records", "Grecords_per_s"}."""
     ms, rec = C.c_float(), C.c_double()

@@ -101,8 +101,12 @@ SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("material_id"
 TEXHDR_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("offset", "<i4")])
 assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.itemsize == 48 and SPHERE_DTYPE.itemsize == 24
 
+# The ABI version THESE hand-written structs were laid out for (include/dsrt.h, DSRT_ABI_VERSION).  load() requires library == header == this, and compares the sizes
+# of the structs above with the library's own (dsrt_sizeof): a header and library bumped without this file are refused, not mis-laid.
+ABI_VERSION = 7
+
 EXPORTS = [
-    "dsrt_last_error", "dsrt_abi_version",
+    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_add_texture_file", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
@@ -116,8 +120,11 @@ EXPORTS = [
 def header_abi_version():
     """DSRT_ABI_VERSION as written in include/dsrt.h -- the one place the number lives; the library returns what it was compiled with."""
     import re
-    with open(os.path.join(os.path.dirname(_HERE), "include", "dsrt.h")) as f:
-        m = re.search(r"^#define\s+DSRT_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    try:
+        with open(os.path.join(os.path.dirname(_HERE), "include", "dsrt.h")) as f:
+            m = re.search(r"^#define\s+DSRT_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    except OSError as e:
+        raise ImportError(f"include/dsrt.h cannot be read ({e}): this binding checks the library against the header it was written for") from e
     if not m:
         raise ImportError("include/dsrt.h does not define DSRT_ABI_VERSION")
     return int(m.group(1))
@@ -139,6 +146,8 @@ def load():
 
     sig("dsrt_last_error", C.c_char_p, [])
     sig("dsrt_abi_version", C.c_int, [])
+    sig("dsrt_sizeof", C.c_size_t, [C.c_int])
+    sig("dsrt_microbench_copy", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, P(C.c_float), P(C.c_double)])
     sig("dsrt_host_scene_create", vp, [])
     sig("dsrt_host_scene_destroy", None, [vp])
     sig("dsrt_host_scene_add_obj", C.c_int, [vp, C.c_char_p, C.c_double])
@@ -193,6 +202,10 @@ def load():
     sig("dsrt_build_gpu_scene", C.c_int, [vp, P(GPUCamera), P(C.c_float), P(GPUScene)])
     sig("dsrt_free_gpu_scene", None, [P(GPUScene)])
     have, want = lib.dsrt_abi_version(), header_abi_version()
-    if have != want:
-        raise ImportError(f"{LIB_PATH} was built for ABI {have}, include/dsrt.h says {want}: rebuild with `make lib`")
+    if not (have == want == ABI_VERSION):
+        raise ImportError(f"ABI mismatch: {LIB_PATH} was built for {have}, include/dsrt.h says {want}, capi.py's structs are laid out for {ABI_VERSION}: "
+                          "rebuild with `make lib` / update capi.py")
+    for which, struct in enumerate((DsrtRenderDesc, DsrtStats, GPUScene, GPUCamera, DsrtPose, DsrtFrame)):      # DSRT_SIZEOF_* of include/dsrt.h, in order
+        if lib.dsrt_sizeof(which) != C.sizeof(struct):
+            raise ImportError(f"capi.py lays {struct.__name__} out in {C.sizeof(struct)} bytes, the library in {lib.dsrt_sizeof(which)}: update capi.py")
     return lib

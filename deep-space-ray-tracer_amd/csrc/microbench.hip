@@ -442,6 +442,51 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
     return DSRT_OK;
 }
 
+// Streaming-copy calibration: what this board's HBM delivers to a plain float4 grid-stride copy (16 B per lane per access, read + write counted), the
+// denominator next to the spec's 8 TB/s.  Buffers far beyond the 256 MB Infinity Cache, so that neither side is served on the die.
+__global__ void __launch_bounds__(256) dsrt_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved) {
+    if (bytes < ((size_t)1 << 20) || bytes > ((size_t)1 << 36) || blocks_per_cu < 1 || blocks_per_cu > 64 || reps < 1 || reps > 1000 || !out_ms || !out_bytes_moved) {
+        dsrt::set_error("dsrt_microbench_copy: bad argument");
+        return DSRT_ERR_INVALID;
+    }
+    float4 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (src) (void)hipFree(src);
+        if (dst) (void)hipFree(dst);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    MB_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MB_TRY(hipGetDeviceProperties(&prop, device));
+    const size_t n = bytes / sizeof(float4);
+    MB_TRY(hipMalloc((void**)&src, n * sizeof(float4)));
+    MB_TRY(hipMalloc((void**)&dst, n * sizeof(float4)));
+    MB_TRY(hipMemset(src, 0x3c, n * sizeof(float4)));
+    MB_TRY(hipMemset(dst, 0, n * sizeof(float4)));
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    const int blocks = prop.multiProcessorCount * blocks_per_cu;
+    hipLaunchKernelGGL(dsrt_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);       // warm-up
+    MB_TRY(hipGetLastError());
+    MB_TRY(hipDeviceSynchronize());
+    MB_TRY(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(dsrt_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+    MB_TRY(hipGetLastError());
+    MB_TRY(hipEventRecord(e1, nullptr));
+    MB_TRY(hipEventSynchronize(e1));
+    MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
+    *out_bytes_moved = 2.0 * (double)(n * sizeof(float4)) * (double)reps;
+    cleanup();
+    return DSRT_OK;
+}
+
 extern "C" int dsrt_microbench_valu_kinds(void) { return kValuKinds; }
 extern "C" const char* dsrt_microbench_valu_kind_name(int kind) { return kind >= 0 && kind < kValuKinds ? kValuKindNames[kind] : ""; }
 

@@ -143,6 +143,17 @@ extern "C" {
 
 const char* dsrt_last_error(void) { return dsrt::g_last_error.c_str(); }
 int dsrt_abi_version(void) { return DSRT_ABI_VERSION; }     // include/dsrt.h: the one place the number is written
+size_t dsrt_sizeof(int which) {                              // what a binding's hand-written mirror of a struct must measure
+    switch (which) {
+        case DSRT_SIZEOF_RENDER_DESC: return sizeof(DsrtRenderDesc);
+        case DSRT_SIZEOF_STATS: return sizeof(DsrtStats);
+        case DSRT_SIZEOF_GPU_SCENE: return sizeof(GPUScene);
+        case DSRT_SIZEOF_GPU_CAMERA: return sizeof(GPUCamera);
+        case DSRT_SIZEOF_POSE: return sizeof(DsrtPose);
+        case DSRT_SIZEOF_FRAME: return sizeof(DsrtFrame);
+        default: return 0;
+    }
+}
 
 DsrtHostScene* dsrt_host_scene_create(void) { return new DsrtHostScene(); }
 void dsrt_host_scene_destroy(DsrtHostScene* hs) { delete hs; }

@@ -35,10 +35,19 @@ const char* dsrt_last_error(void);
 /* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
  * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
  * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended;
- * 6 = dsrt_host_scene_add_texture_file).  dsrt_abi_version() returns the value the library was compiled with;
+ * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
-#define DSRT_ABI_VERSION 6
+#define DSRT_ABI_VERSION 7
 int dsrt_abi_version(void);
+/* sizeof of the structs that cross this ABI, as the LIBRARY was compiled: a binding that mirrors them by hand (ctypes, cgo, JNA ...) compares its own sizes with
+ * these at load time, so that a struct that grew in the header and the library but not in the binding is refused instead of silently mis-laid.  0 = unknown. */
+#define DSRT_SIZEOF_RENDER_DESC 0
+#define DSRT_SIZEOF_STATS       1
+#define DSRT_SIZEOF_GPU_SCENE   2
+#define DSRT_SIZEOF_GPU_CAMERA  3
+#define DSRT_SIZEOF_POSE        4
+#define DSRT_SIZEOF_FRAME       5
+size_t dsrt_sizeof(int which);
 
 /* ===================================================================================== */
 /* Host scene assembly -- no GPU involved.                                               */
@@ -358,6 +367,12 @@ int dsrt_microbench_valu(int device, int kind, int pattern, int waves_per_simd, 
                          double* out_shader_clock_GHz);
 int dsrt_microbench_valu_kinds(void);
 const char* dsrt_microbench_valu_kind_name(int kind);
+
+/* The third calibration: what this board's HBM delivers to a plain streaming copy -- a float4 grid-stride kernel (16 bytes per lane per access), `blocks_per_cu`
+ * 256-thread workgroups per CU, `bytes` per buffer (take it far beyond the 256 MB Infinity Cache), `reps` launches back to back.  Returns the time (HIP events)
+ * and the bytes moved (read + written).  The figure bench.py prints as extras.hbm_copy_GBps_measured, next to the 8 TB/s of the specification.
+ * No reference interface: measurement only. */
+int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */

@@ -1,7 +1,8 @@
 /*
  * dsrt_oracle.c -- CPU restatement of the reference renderer's sampling loop.
- * TEST INFRASTRUCTURE ONLY; see dsrt_oracle.h for who may use it and for the pinning status
- * ("parity unpinned" for the loop itself; its inputs are pinned through oracle/_ref).
+ * TEST INFRASTRUCTURE ONLY; see dsrt_oracle.h for who may use it and for the pinning status: PINNED -- its images equal, byte for byte,
+ * those the reference's own kernel rendered (tests/golden/ref_gpu_detmath_images.json, checked by tests/test_oracle_reference_fixtures.py in
+ * the CPU suite), and everything that feeds the loop is pinned through oracle/_ref/ref_host (tests/golden/ref_*).
  *
  * Every function names the lines of /root/reference/src/gpu_render.cu it follows.  The data walk
  * is the reference's: 40-byte AoS BVH nodes, 116-byte AoS triangles, tri_indices indirection,

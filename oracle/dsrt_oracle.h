@@ -29,13 +29,17 @@
  *         inc/material.h:28-32, 123-180, inc/onb.h:47-56; tests/golden/ref_matkat.json): bit for bit where
  *         the host arithmetic is float (everything but reflectance, which is double: to 3e-7); build_onb's u
  *         is the exact negative of the class's (cross(v, w) against cross(w, v)).
- *   - CONTROL FLOW AND ORDER (ray_color :715-936, scene_hit :509-551, the traversal order of bvh_hit_closest :387-473) are pinned
- *     one level up, by executing the reference's own kernel: oracle/_ref/ref_gpu (src/gpu_render.cu and src/gpu_scene_builder.cpp
- *     translated CUDA -> HIP by the image's hipify-perl and compiled with hipcc, oracle/Makefile) renders the same bytes as the HIP
- *     kernel built against the same device math library (tests/test_gpu_reference_kernel.py; the whole 1080p x 1000 spp headline
- *     frame: profiles/r03/reference_kernel_hipified_headline_frame.json), and the HIP kernel's product build equals THIS restatement
- *     bit for bit (tests/test_gpu_parity.py).  This file cannot be compared with ref_gpu directly -- it runs on the CPU and uses
- *     dsrt_detmath.h where ref_gpu uses the device math library -- so its pin is that two-step chain plus the leaves above.
+ *   - CONTROL FLOW AND ORDER (ray_color :715-936, scene_hit :509-551, the traversal order of bvh_hit_closest :387-473), i.e. THE LOOP AS A WHOLE, are pinned
+ *     by images the reference's own kernel rendered, committed as data:
+ *       * DIRECTLY: oracle/_ref/ref_gpu_detmath is the reference's renderer (src/gpu_render.cu and src/gpu_scene_builder.cpp translated CUDA -> HIP by the
+ *         image's hipify-perl, compiled with hipcc -ffp-contract=off: oracle/Makefile) with its three libm names (cosf, sinf, powf) mapped onto
+ *         include/dsrt_detmath.h by ref_gpu_detmath_prelude.h -- the functions THIS file uses.  Its images of the six parity scenes, 30 randomised views and the
+ *         station on pose frames are in tests/golden/ref_gpu_detmath_images.json (made on an MI355X by tests/golden/make_ref_gpu_fixtures.py), and this
+ *         restatement reproduces them byte for byte in the CPU suite (tests/test_oracle_reference_fixtures.py): one hop, no product code in between.
+ *       * and through the product: oracle/_ref/ref_gpu (the same build with the device math library) == the HIP kernel in math_mode 1, byte for byte
+ *         (tests/golden/ref_gpu_images.json, tests/test_gpu_reference_fixtures.py, live: tests/test_gpu_reference_kernel.py), whose math_mode 0 build equals
+ *         THIS restatement bit for bit (tests/test_gpu_parity.py).
+ *     What no fixture can cover: a real CUDA run (nvcc contracts to FMA by default, libdevice math; no NVIDIA GPU exists in this pipeline).
  *   - cosf/sinf/powf come from include/dsrt_detmath.h (shared with the HIP kernel), not from any
  *     libm: see that header.  Build with -DDSRT_ORACLE_LIBM to use the host libm instead (for the
  *     statistical comparison only).

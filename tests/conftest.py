@@ -95,3 +95,15 @@ def load_world(dsrt, name):
     finally:
         os.chdir(cwd)
     return hs
+
+
+def require_ref_binary(path):
+    """The live reference binaries (oracle/_ref/, built where /root/reference exists and carried to the GPU box by the gpurun snapshot) are part of the parity pin:
+    under -m gpu their absence is a FAILURE, not a skip -- a box that lost them would otherwise report green with the pin gone.  A clean checkout that is known
+    not to have them (the committed fixtures of tests/test_gpu_reference_fixtures.py still check the loop there) says so with DSRT_ALLOW_NO_REF=1."""
+    if os.path.exists(path):
+        return
+    if os.environ.get("DSRT_ALLOW_NO_REF") == "1":
+        pytest.skip(f"{os.path.relpath(path, ROOT)} not built and DSRT_ALLOW_NO_REF=1")
+    pytest.fail(f"{os.path.relpath(path, ROOT)} is missing: build it with `make -C oracle` where /root/reference exists (it travels with the gpurun snapshot), "
+                "or set DSRT_ALLOW_NO_REF=1 to run without the live reference binaries")

@@ -9,8 +9,8 @@ GPUCamera for all 99 poses; flattened triangles / materials / spheres / texture 
 tri_indices) for the asset scenes; ray-level answers of the reference's CPU classes.  The inputs (assets/) are ours:
 small OBJ/MTL/PPM/PNG files and "world description" files written by this script.
 
-What is NOT reference-made: anything about the render loop itself (the CUDA kernel cannot be built here) -- see
-oracle/dsrt_oracle.h.
+What is NOT made here: the render loop's reference-made images.  Those need a GPU: tests/golden/make_ref_gpu_fixtures.py runs the reference's
+own kernel (oracle/_ref/ref_gpu, ref_gpu_detmath) on an MI355X and writes ref_gpu_images.json / ref_gpu_detmath_images.json -- see oracle/dsrt_oracle.h.
 """
 import hashlib
 import json

@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ASSETS, load_world
+from conftest import ASSETS, load_world, require_ref_binary
 from test_oracle import CASES, SUN
 
 pytestmark = pytest.mark.gpu
@@ -65,8 +65,7 @@ def _our_image(dsrt, gpu_ctx, name, math_mode):
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_kernel_and_this_kernel_give_the_same_bytes(dsrt, gpu_ctx, name, tmp_path):
-    if not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_gpu not built (oracle/Makefile builds it where /root/reference and hipify-perl exist)")
+    require_ref_binary(REF_GPU)
     ref = _reference_image(name, tmp_path)
     ours = _our_image(dsrt, gpu_ctx, name, 1)
     assert ref.shape == ours.shape
@@ -82,8 +81,7 @@ def test_reference_kernel_on_the_bench_mesh_pose_frames(dsrt, gpu_ctx, tmp_path,
     fills the view) and 60 (715 m) of the reference's pose file, 640 x 360 at 32 samples; and THE BENCH'S MESH -- 1,000,308 triangles, a tree that needs 18 stack
     entries -- at the bench's size, frame 98, 12 samples; max_depth 50 -- every byte.  (The whole headline frame at 1000 samples: tools/reference_kernel_probe.py
     --spp 1000 --compare, profiles/r03/reference_kernel_hipified_headline_frame.json: 0 of 2,073,600 pixels differ.)"""
-    if not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_gpu not built")
+    require_ref_binary(REF_GPU)
     from dsrt_amd import meshgen
     from conftest import GOLDEN
     if tris == 1000000:                                       # the file bench.py and test_headline_mesh_rows_match_the_oracle use
@@ -121,8 +119,7 @@ def test_reference_kernel_on_the_bench_mesh_pose_frames(dsrt, gpu_ctx, tmp_path,
 def test_math_mode_0_differs_from_the_reference_kernel_only_statistically(dsrt, gpu_ctx, tmp_path):
     """The default mode (deterministic sin / cos / pow shared with the CPU oracle) against the reference kernel with the device math library: one differing ulp
     in cosf de-synchronises the rest of a pixel's random stream, so some pixels differ -- but the images are the same picture."""
-    if not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_gpu not built")
+    require_ref_binary(REF_GPU)
     name = "station_near"
     ref = _reference_image(name, tmp_path).astype(np.int32)
     ours = _our_image(dsrt, gpu_ctx, name, 0).astype(np.int32)
@@ -135,8 +132,8 @@ def test_a_contracted_build_of_the_reference_is_the_same_picture_not_the_same_by
     kernel compiled that way (-ffp-contract=fast, everything else as ref_gpu).  Against the strict build of the SAME source its image differs in some pixels -- one
     rounding moves a sample across a branch and the rest of that pixel's random stream follows -- while mean level and coverage agree: the reason the product states
     a bit-exact contract (the reference's operations, uncontracted) and calls the comparison with any contracted or other-libm build statistical."""
-    if not (os.path.exists(REF_GPU) and os.path.exists(REF_GPU_FMA)):
-        pytest.skip("oracle/_ref/ref_gpu or ref_gpu_fma not built")
+    require_ref_binary(REF_GPU)
+    require_ref_binary(REF_GPU_FMA)
     name = "station_near"
     strict = _reference_image(name, tmp_path).astype(np.int32)
     fused = _reference_image(name, tmp_path, REF_GPU_FMA).astype(np.int32)
@@ -151,23 +148,9 @@ def test_randomised_views_of_every_world_match_the_reference_kernel(dsrt, gpu_ct
     3k-triangle station, the `quirks` mesh with its degenerate and duplicated faces), ragged image sizes, 1 to 24 samples, depths 1 to 50, cameras from inside
     the geometry to far outside, random un-normalised sun directions -- each rendered by the reference's own kernel (one ref_gpu process per view) and by this
     library in math_mode 1, byte for byte."""
-    if not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_gpu not built")
-    rng = np.random.default_rng(20251005)
-    worlds = ("c1_spheres", "lights", "station_3k", "textured", "mixed", "quirks")
-    f32 = lambda v: float(np.float32(v))                      # noqa: E731 -- every number crosses both command lines as an exactly representable float
-    jobs = []
-    for trial in range(30):
-        world = worlds[trial % len(worlds)]
-        W, H = int(rng.integers(8, 150)), int(rng.integers(6, 100))
-        spp = int(rng.choice([1, 2, 5, 9, 24]))
-        depth = int(rng.choice([1, 2, 5, 12, 50]))
-        dist = float(rng.choice([0.5, 3.0, 9.0, 30.0, 120.0, 600.0])) * (0.15 if world in ("c1_spheres", "lights", "textured", "mixed") else 1.0)
-        direction = rng.normal(size=3)
-        direction /= np.linalg.norm(direction)
-        jobs.append({"trial": trial, "world": world, "W": W, "H": H, "spp": spp, "depth": depth, "from": [f32(v) for v in direction * dist + (0.0, 1.0, 0.0)],
-                     "at": [f32(v) for v in rng.normal(size=3) * (0.0 if trial % 3 else 0.5)], "vfov": f32(rng.choice([20.0, 40.0, 75.0])),
-                     "sun": [f32(v) for v in rng.normal(size=3)]})
+    require_ref_binary(REF_GPU)
+    import ref_gpu_jobs as J
+    jobs = [dict(j, trial=int(j["key"].split("/")[1])) for j in J.fuzz_jobs()]       # the same 30 views the committed fixtures hold (tests/ref_gpu_jobs.py)
     cache = {}
     failures, lit_total = [], 0
     for j in jobs:
@@ -190,11 +173,23 @@ def test_randomised_views_of_every_world_match_the_reference_kernel(dsrt, gpu_ct
     assert lit_total > 20000                                   # the views do see things
 
 
+@pytest.mark.parametrize("name", ["station_near", "mixed", "lights"])
+def test_reference_kernel_with_the_shared_math_header_equals_the_default_mode(dsrt, gpu_ctx, name, tmp_path):
+    """oracle/_ref/ref_gpu_detmath -- the reference's kernel with its three libm calls mapped onto include/dsrt_detmath.h -- live, against this library's DEFAULT mode
+    (math_mode 0, the benched one).  The committed form of this comparison, all 40 images: tests/test_gpu_reference_fixtures.py; the CPU oracle against the same
+    images: tests/test_oracle_reference_fixtures.py."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_gpu_detmath")
+    require_ref_binary(exe)
+    ref = _reference_image(name, tmp_path, exe)
+    ours = _our_image(dsrt, gpu_ctx, name, 0)
+    differing = int((ref != ours).any(axis=2).sum())
+    assert differing == 0 and int((ref.max(axis=2) > 0).sum()) > 150, (name, differing)
+
+
 def test_the_drop_in_gpu_render_scene_writes_the_reference_s_file(dsrt, tmp_path):
     """The reference's three calls (src/main.cpp:405-428) through THIS library -- dsrt_build_gpu_scene, gpu_render_scene, dsrt_free_gpu_scene -- with DSRT_MATH_MODE=1,
     against the same three calls of the reference's own code (ref_gpu): image_gpu.ppm, the whole file, header included."""
-    if not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_gpu not built")
+    require_ref_binary(REF_GPU)
     import ctypes as C
     name = "mixed"
     world, cam_args, spp = CASES[name]

@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, require_ref_binary
 from test_gpu_reference_kernel import REF_GPU, _read_ppm
 
 pytestmark = pytest.mark.gpu
@@ -56,8 +56,7 @@ def _pose_lines():
 
 
 def test_the_reference_main_renders_its_frames_through_this_library(dsrt, gpu_ctx, tmp_path):
-    if not os.path.exists(REF_MAIN):
-        pytest.skip("oracle/_ref/ref_main_on_dsrt not built (oracle/Makefile builds it where /root/reference exists)")
+    require_ref_binary(REF_MAIN)
     obj, out, log = _run_main(tmp_path, _pose_lines(), math_mode=0)
     hs = dsrt.HostScene().add_obj(obj)                       # this library's own loader, flattener and builder on the same file
     hs.build_bvh()
@@ -79,8 +78,8 @@ def test_the_reference_main_renders_its_frames_through_this_library(dsrt, gpu_ct
 def test_the_reference_main_on_this_library_writes_what_the_reference_program_writes(tmp_path):
     """With the device math library selected (DSRT_MATH_MODE=1) the frame main() writes through this library is, byte for byte, the frame the reference's whole
     program (its own builder and its own kernel, oracle/_ref/ref_gpu) writes for the same mesh, camera and sun."""
-    if not os.path.exists(REF_MAIN) or not os.path.exists(REF_GPU):
-        pytest.skip("oracle/_ref/ref_main_on_dsrt or oracle/_ref/ref_gpu not built")
+    require_ref_binary(REF_MAIN)
+    require_ref_binary(REF_GPU)
     import dsrt_amd as d
     lines = _pose_lines()[2:]                                # the near pose
     obj, out, _ = _run_main(tmp_path, lines, math_mode=1)
@@ -128,8 +127,7 @@ def _textured_panels(obj):
 def test_textured_and_metal_materials_through_the_reference_loader_and_main(dsrt, gpu_ctx, tmp_path):
     """The reference's OBJ / MTL loader (Ks -> metal, map_Kd -> per-triangle texture path, uv stored as (u, 1 - v)) and its stb flip flag on one side, this library's
     loader on the other, same files: the frames must be the same bytes.  Exercises dsrt_host_scene_add_texture_file behind build_gpu_scene."""
-    if not os.path.exists(REF_MAIN):
-        pytest.skip("oracle/_ref/ref_main_on_dsrt not built")
+    require_ref_binary(REF_MAIN)
     obj, out, log = _run_main(tmp_path, _pose_lines()[2:], math_mode=0, write_mesh=_textured_panels)
     theirs = _read_ppm(out / "frame_0000.ppm")
     hs = dsrt.HostScene().add_obj(obj)

@@ -2,8 +2,9 @@
 
 Reference-made pins: the LCG values SURVEY.md section 8(a2) records; ray-level answers of the reference's CPU classes
 (tests/golden/ref_hitkat.json: aabb::hit is the same float algorithm -> exact; sphere::hit / triangle::hit compute in
-double from float inputs -> agreement to rounding).  The sampling loop as a whole has no reference-made vector (see
-oracle/dsrt_oracle.h): the image hashes at the bottom are regression fixtures produced by this oracle itself.
+double from float inputs -> agreement to rounding).  The sampling loop as a whole is pinned by reference-made images in
+tests/test_oracle_reference_fixtures.py (the reference's own kernel, executed; see oracle/dsrt_oracle.h); the image hashes at the
+bottom of THIS file are regression fixtures produced by the oracle itself.
 """
 import ctypes as C
 import hashlib
@@ -175,7 +176,7 @@ def test_device_helper_known_answers_from_the_reference(oracle):
     (:190-202), generate_camera_ray_device with lens_radius 0 (inc/camera.h:35-61).  The kernel has float copies of the same formulas
     (src/gpu_render.cu:77-109, 941-968) which the oracle restates.  Exact where the arithmetic is float or exact (LCG, rejection loop,
     camera ray); to rounding where the helper works in double (cosine direction: cos/sin/sqrt in double rounded once vs the oracle's
-    float sqrt and shared deterministic sin/cos).  What stays unpinned after this: ray_color's control flow and the traversal order."""
+    float sqrt and shared deterministic sin/cos).  ray_color's control flow and the traversal order are pinned by the reference kernel's images (tests/test_oracle_reference_fixtures.py)."""
     kat = json.load(open(os.path.join(GOLDEN, "ref_devkat.json")))
     L = oracle.lib
     for fn in (L.dsrt_oracle_random_in_unit_sphere, L.dsrt_oracle_random_cosine_direction):
@@ -358,6 +359,6 @@ def check_material_known_answers(impl, normalize):
 
 def test_material_and_frame_known_answers_from_the_reference(oracle):
     """What ray_color's specular branches and the cosine sampler are made of, pinned by the reference's own host code, executed:
-    after this the unpinned part of the oracle is ray_color's control flow, scene_hit's combination and the traversal order -- nothing else."""
+    what these leaves leave open -- ray_color's control flow, scene_hit's combination, the traversal order -- is pinned by the reference kernel's images (tests/test_oracle_reference_fixtures.py)."""
     impl = OracleMatkat(oracle)
     check_material_known_answers(impl, impl.normalize)
