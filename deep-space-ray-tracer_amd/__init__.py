@@ -208,6 +208,11 @@ def selftest_rccl_gather(device=0, nbytes=1 << 20):
     _check(lib.dsrt_selftest_rccl_gather(int(device), int(nbytes)), "dsrt_selftest_rccl_gather")
 
 
+def set_experiment(word):
+    """Development switches of the A/B tools (include/dsrt.h, dsrt_dev_set_experiment): process-wide, undefined bits refused."""
+    _check(lib.dsrt_dev_set_experiment(int(word) & 0xFFFFFFFF), "dsrt_dev_set_experiment")
+
+
 def microbench_copy(nbytes=2 << 30, blocks_per_cu=8, reps=8, device=0):
     """HBM streaming-copy calibration (include/dsrt.h): float4 grid-stride copy; GB/s counts bytes read + written."""
     ms, moved = C.c_float(), C.c_double()
@@ -316,6 +321,12 @@ class Context:
         _check(rc, "dsrt_render_to_host")
         shape = (desc.height, desc.width, 3)
         return rgb.reshape(shape), (f32.reshape(shape) if want_f32 else None), st
+
+    def poke_node_word(self, word_index, value):
+        """Test hook (dsrt_selftest_poke_node_word): overwrite one 32-bit word of the resident node records; returns the previous value."""
+        old = C.c_uint32()
+        _check(lib.dsrt_selftest_poke_node_word(self._h, int(word_index), int(value) & 0xFFFFFFFF, C.byref(old)), "dsrt_selftest_poke_node_word")
+        return old.value
 
     def selftest_philox(self, seed, subsequence, n):
         ours, theirs = np.zeros(n, np.uint32), np.zeros(n, np.uint32)

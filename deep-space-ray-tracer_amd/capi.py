@@ -106,7 +106,7 @@ assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.ite
 ABI_VERSION = 7
 
 EXPORTS = [
-    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy",
+    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_add_texture_file", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
@@ -147,6 +147,8 @@ def load():
     sig("dsrt_last_error", C.c_char_p, [])
     sig("dsrt_abi_version", C.c_int, [])
     sig("dsrt_sizeof", C.c_size_t, [C.c_int])
+    sig("dsrt_dev_set_experiment", C.c_int, [C.c_uint32])
+    sig("dsrt_selftest_poke_node_word", C.c_int, [vp, C.c_size_t, C.c_uint32, P(C.c_uint32)])
     sig("dsrt_microbench_copy", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, P(C.c_float), P(C.c_double)])
     sig("dsrt_host_scene_create", vp, [])
     sig("dsrt_host_scene_destroy", None, [vp])

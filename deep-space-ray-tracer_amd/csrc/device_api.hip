@@ -8,6 +8,7 @@
 // not only printed; the launch is asynchronous on a caller-supplied stream; output goes to caller-owned buffers.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,9 +24,9 @@
 #include "device_layout.h"
 
 namespace dsrt {
-hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
-hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
-hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, bool lean, hipStream_t stream);
+hipError_t launch_probe(const RenderArgs& a, int blocks, bool lean, hipStream_t stream);
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, bool lean, hipStream_t stream);
 hipError_t launch_batch_table(BatchFrame* table, const uint32_t* sched, uint32_t sched_stride, uint32_t frames, uint32_t tt, int rng_mode, int spp, int light_chunk_len,
                               uint32_t* total_items, hipStream_t stream);
 hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
@@ -41,9 +42,9 @@ hipError_t launch_tile_reorder(const uint32_t* work, uint32_t* order, uint32_t* 
 hipError_t launch_content_hash(const uint32_t* words, size_t n_words, uint64_t salt, uint64_t* d_hash2, hipStream_t stream);
 // DsrtRenderDesc.math_mode 1: the same kernels compiled against the device math library's sinf / cosf / powf (render_kernel.hip, second compilation)
 namespace devlibm {
-hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream);
-hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream);
-hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, bool lean, hipStream_t stream);
+hipError_t launch_probe(const RenderArgs& a, int blocks, bool lean, hipStream_t stream);
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, bool lean, hipStream_t stream);
 hipError_t launch_resolve(const unsigned long long* sums, int spp, float inv_gamma, size_t n_pixels, uint8_t* out_rgb8, float* out_f32, hipStream_t stream);
 }  // namespace devlibm
 }  // namespace dsrt
@@ -104,6 +105,7 @@ struct PackedScene {
     GPUCamera camera{};
     DsrtF3 sun_dir{}, sun_radiance{};
     int sun_enabled = 0;
+    bool lean = false;              // no spheres, no textures, Lambertian materials only: the production launches use the kernels' LEAN instantiation (path_machine.h)
     bool valid = false;
 };
 
@@ -263,6 +265,8 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
     v.num_textures = (int)out.tex_headers.n; v.tex_pool_floats = (int)out.tex_pool.n;
     out.camera = h.camera;
     out.sun_dir = h.sun_dir; out.sun_radiance = h.sun_radiance; out.sun_enabled = h.sun_enabled ? 1 : 0;
+    out.lean = h.num_spheres == 0 && out.tex_headers.n == 0;
+    for (int i = 0; i < h.num_materials && out.lean; ++i) out.lean = h.materials[i].type == MAT_LAMBERTIAN;
     out.valid = true;
     return DSRT_OK;
 }
@@ -322,29 +326,58 @@ bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
     return true;
 }
 
-// Development switches.  They are NOT part of the ABI (include/dsrt.h refuses unknown bits of DsrtRenderDesc.tune[3]); the A/B tools
-// under tools/ set them through the environment variable DSRT_EXPERIMENT (an integer in C syntax, read at every render call):
+// Development switches.  They are NOT part of a render's description (include/dsrt.h refuses unknown bits of DsrtRenderDesc.tune[3]); the A/B tools under
+// tools/ set them through dsrt_dev_set_experiment(), and a process started with the environment variable DSRT_EXPERIMENT (an integer in C syntax) takes that as
+// the initial word -- read ONCE, in the first dsrt_device_count / dsrt_ctx_create call, never per render.  Undefined bits are refused, and a non-zero word is
+// announced on stderr, so that a stray variable cannot silently change how a production process schedules its work.
 //   64           8 probe samples per pixel instead of 4
 //   128          leaf records are not dealt to idle lanes (render_kernel.hip, phase L)
 // (the low six bits are never used here: tools/ab_tune.py splits one number into the DSRT_TUNE_* flags and this word)
 //   bits 8-19    rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass)
 //   bits 20-22   grid = resident set >> n (frames that overlap on separate streams)
-//   bit 27       counting build of rng_mode 0: the float image receives per pixel (fetch time, end time, wave) as bit patterns,
-//                100 MHz ticks, instead of the colour (tools/chain_timeline.py)
+//   bit 24       the general kernels even for a scene that qualifies for the LEAN instantiation (A/B of the two)
+//   bit 27       COUNTING BUILD of rng_mode 0 only: the float image receives per pixel (fetch time, end time, wave) as bit patterns,
+//                100 MHz ticks, instead of the colour (tools/chain_timeline.py) -- the one switch that changes output (the float image; never the bytes)
 //   bits 28-29   rng_mode 1: least samples per work item of a background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512
 //   bit 31       rng_mode 1: background pixels one item each
-// None of them changes a pixel either (tests/test_gpu_parity.py runs the render under several of them against the oracle).
-uint32_t experiment_word() {
-    const char* e = std::getenv("DSRT_EXPERIMENT");
-    return e && *e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
+// Apart from bit 27 none of them changes a pixel (tests/test_gpu_parity.py runs the render under several of them against the oracle).
+constexpr uint32_t kExperimentDefined = 64u | 128u | (0xFFFu << 8) | (7u << 20) | (1u << 24) | (1u << 27) | (3u << 28) | (1u << 31);
+std::atomic<uint32_t> g_experiment{0u};
+
+int set_experiment(uint32_t word, const char* from) {
+    if (word & ~kExperimentDefined) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "%s: development switch word 0x%x has undefined bits (defined: 0x%x)", from, word, kExperimentDefined);
+        set_error(buf);
+        return DSRT_ERR_INVALID;
+    }
+    if (word != g_experiment.exchange(word) && word) std::fprintf(stderr, "libdsrt_hip: development switches 0x%x in effect (%s)\n", word, from);
+    return DSRT_OK;
 }
+
+void experiment_from_environment() {            // once per process
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* e = std::getenv("DSRT_EXPERIMENT");
+        if (e && *e && set_experiment((uint32_t)std::strtoul(e, nullptr, 0), "environment variable DSRT_EXPERIMENT") != DSRT_OK)
+            std::fprintf(stderr, "libdsrt_hip: DSRT_EXPERIMENT ignored: %s\n", dsrt_last_error());
+    });
+}
+
+uint32_t experiment_word() { return g_experiment.load(); }
 
 }  // namespace
 
 extern "C" {
 
+int dsrt_dev_set_experiment(uint32_t word) {
+    experiment_from_environment();              // (so that a later first context does not overwrite this call's word with the variable's)
+    return set_experiment(word, "dsrt_dev_set_experiment");
+}
+
 int dsrt_device_count(void) {
     hw_queues_default();
+    experiment_from_environment();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -354,6 +387,7 @@ int dsrt_ctx_create(int device, DsrtContext** out) {
     if (!out) { set_error("dsrt_ctx_create: null out"); return DSRT_ERR_INVALID; }
     *out = nullptr;
     hw_queues_default();
+    experiment_from_environment();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return DSRT_ERR_NO_DEVICE; }
     if (device < 0 || device >= n) { set_error("device index out of range"); return DSRT_ERR_INVALID; }
@@ -464,6 +498,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     if (desc->rng_mode != 0 && desc->rng_mode != 1) { set_error("dsrt_render: rng_mode must be 0 (reference LCG stream per pixel) or 1 (Philox4x32-10 stream per sample)"); return DSRT_ERR_INVALID; }
     if (desc->math_mode != 0 && desc->math_mode != 1) { set_error("dsrt_render: math_mode must be 0 (deterministic sin / cos / pow shared with the CPU oracle) or 1 (the device math library's)"); return DSRT_ERR_INVALID; }
     const bool libm = desc->math_mode == 1;
+    const bool lean = ctx->scene->lean && !(experiment_word() & (1u << 24));
     if (desc->tune[3] & ~DSRT_TUNE_FLAG_MASK) { set_error("dsrt_render: tune[3] has bits set that this ABI version does not define (DSRT_TUNE_* in include/dsrt.h)"); return DSRT_ERR_INVALID; }
     const uint32_t flags = (uint32_t)desc->tune[3];
     const uint32_t xp = experiment_word();
@@ -575,7 +610,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 10;            // (16 until the node loop looked at its votes every other iteration: profiles/r03/ab_loop_knobs_after_unroll.jsonl)
     a.deal_leaves = (xp & 128u) ? 0 : 1;                        // (development switch 128: the leaf pass without dealing, for A/B runs)
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
-    a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | ((xp & (1u << 27)) ? 8 : 0);      // (8: timing image, counting build)
+    a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
     // Interleaved medians, 1080p x 1000: near frame 1117 -> 1108 ms, frame 95 801 -> 785 ms.  Finer grades (the top quarter and sixteenth of
     // the order above the rest) were tried in round 2 and moved nothing consistently (profiles/r02/ab_issue_priority.jsonl); they are gone.
@@ -635,7 +670,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
                 HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
                 HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
                 HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
-                HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, stream) : launch_probe(pa, blocks, stream));
+                HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, lean, stream) : launch_probe(pa, blocks, lean, stream));
                 HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p + pre_stride * (size_t)i, ctx->tile_tmp.p, sched + pre_stride * (size_t)i, stream));
             }
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
@@ -672,7 +707,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
             HIP_TRY(hipMemsetAsync(ctx->probe_queue.p, 0, 1024 * sizeof(uint32_t), stream));
             pa.probe_queue = ctx->probe_queue.p;
             HIP_TRY(hipMemsetAsync(ctx->tile_work.p, 0, (size_t)t.mine * sizeof(uint32_t), stream));
-            HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, stream) : launch_probe(pa, blocks, stream));
+            HIP_TRY(libm ? devlibm::launch_probe(pa, blocks, lean, stream) : launch_probe(pa, blocks, lean, stream));
             HIP_TRY(launch_tile_reorder(ctx->tile_work.p, ctx->tile_order.p, ctx->tile_tmp.p, sched, stream));
             HIP_TRY(hipMemsetAsync(ctx->ctrl.p, 0, kCtrlWords * sizeof(uint32_t), stream));
         }
@@ -684,9 +719,9 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     }
     if (stats) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     const bool count = desc->collect_counters != 0;
-    if (batch) HIP_TRY(libm ? devlibm::launch_render_batch(a, desc->rng_mode, blocks, stream) : launch_render_batch(a, desc->rng_mode, blocks, stream));
-    else if (libm) HIP_TRY(devlibm::launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
-    else HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, stream));
+    if (batch) HIP_TRY(libm ? devlibm::launch_render_batch(a, desc->rng_mode, blocks, lean, stream) : launch_render_batch(a, desc->rng_mode, blocks, lean, stream));
+    else if (libm) HIP_TRY(devlibm::launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, lean, stream));
+    else HIP_TRY(launch_render(a, K, desc->rng_mode, blocks, count, count || desc->checked != 0, desc->collect_counters != 2, lean, stream));
     if (desc->rng_mode == 1) HIP_TRY(libm ? devlibm::launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream)
                                           : launch_resolve(a.accum_fixed, f.spp, f.inv_gamma, out_pixels, d_rgb8, d_f32, stream));
     HIP_TRY(hipEventRecord(ctx->done, stream));
@@ -811,6 +846,17 @@ int dsrt_render_to_host(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* h
     if (h_f32) HIP_TRY(hipMemcpy(h_f32, d32.p, px * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return DSRT_OK;
     });
+}
+
+int dsrt_selftest_poke_node_word(DsrtContext* ctx, size_t word_index, uint32_t value, uint32_t* old_value) {
+    if (!ctx || !ctx->scene || !ctx->scene->valid) { set_error("dsrt_selftest_poke_node_word: no scene uploaded"); return DSRT_ERR_NO_SCENE; }
+    if (word_index >= ctx->scene->pairs.n * 4) { set_error("dsrt_selftest_poke_node_word: word index beyond the node records"); return DSRT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t* w = reinterpret_cast<uint32_t*>(ctx->scene->pairs.p) + word_index;
+    if (old_value) HIP_TRY(hipMemcpy(old_value, w, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(w, &value, 4, hipMemcpyHostToDevice));
+    return DSRT_OK;
 }
 
 int dsrt_selftest_math(DsrtContext* ctx, int fn, const float* x, float y, float* out, int n) {

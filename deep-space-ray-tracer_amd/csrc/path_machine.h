@@ -106,9 +106,14 @@ __device__ __forceinline__ typename RngOf<RNGMODE>::type make_rng(Lane& ln, cons
     }
 }
 
-template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
+// LEAN: instantiation for scenes that have no spheres (hence no sphere lights), no textures and only Lambertian materials -- decided once, at upload
+// (device_api.hip: pack_scene) -- which is what an OBJ mesh with plain Kd materials is, the headline mesh included.  The blocks for the other material
+// classes, the sphere loops, the mixture branch and the texture fetch are then not compiled at all: exact by construction (they are the branches such a scene
+// never takes) and ~20 scalar registers the advance pass no longer keeps alive.
+template <bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false, bool LEAN = false>
 __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, uint32_t* c, uint32_t& flags) {
     const DeviceScene& S = args.scene;
+    const int num_spheres = LEAN ? 0 : S.num_spheres;
     const FrameParams& P = args.frame;
     int& state = ln.state; int& px = ln.px; int& ky = ln.ky; int& sample = ln.sample; int& depth = ln.depth;
     uint32_t& out_index = ln.out_index;
@@ -163,13 +168,13 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
         bool blocked = hit_slot >= 0;
         if (!blocked || !ANYHIT) {
-            for (int i = 0; i < S.num_spheres; ++i) {
+            for (int i = 0; i < num_spheres; ++i) {
                 if (COUNT) c[C_SPHERE_TESTS]++;
                 float t_hit; F3 n_hit;
                 if (hit_sphere(S.spheres[i], ro, rd, closest, t_hit, n_hit)) { blocked = true; closest = t_hit; }
             }
         } else if (COUNT) {
-            c[C_SPHERE_TESTS] += (uint32_t)S.num_spheres;
+            c[C_SPHERE_TESTS] += (uint32_t)num_spheres;
         }
         const uint32_t owner_plus1 = (ln.aux >> 16) & 0x7Fu;
         if (owner_plus1) {                                    // traced for another lane: hand the answer over, be free again
@@ -207,7 +212,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             tex_id = __float_as_int(a2.z);
             hit_any = true;
         }
-        for (int i = 0; i < S.num_spheres; ++i) {
+        for (int i = 0; i < num_spheres; ++i) {
             if (COUNT) c[C_SPHERE_TESTS]++;
             const GPUSphere sph = S.spheres[i];
             float t_hit; F3 n_hit;
@@ -228,13 +233,13 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             if (CHECKED && (unsigned)mat_id >= (unsigned)S.num_materials) { flags |= kFlagBadMaterial; mat_id = 0; }
             const float4* mp = S.materials + (size_t)mat_id * 3;
             const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-            const int mtype = __float_as_int(m0.x);
+            const int mtype = LEAN ? (int)MAT_LAMBERTIAN : __float_as_int(m0.x);
             if (mtype == MAT_DIFFUSE_LIGHT) {                                                 // :754-758
                 L = L + (thr * mk(m1.w, m2.x, m2.y));
                 end_sample();
             } else {
                 F3 albedo = mk(m1.x, m1.y, m1.z);                                             // :763-774
-                if (tex_id >= 0 && S.tri_uv) {
+                if (!LEAN && tex_id >= 0 && S.tri_uv) {
                     const float4* uvp = S.tri_uv + (size_t)hit_slot * 2;
                     const float4 u0 = uvp[0], u1 = uvp[1];
                     const float wgt = 1.0f - hit_u - hit_v;
@@ -281,7 +286,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
                     //      before tracing it leaves the LCG stream exactly as the reference's order does. ----
                     bool end_after = false;
                     F3 ndir = mk(0, 0, 1), nthr = thr;
-                    if (S.num_lights == 0) {                                                 // :852-866
+                    if (LEAN || S.num_lights == 0) {                                         // :852-866
                         float pdf;
                         ndir = sample_cosine_hemisphere(hn, rng, pdf);
                         if (pdf <= 0.0f) end_after = true;
@@ -610,7 +615,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
             if (slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state = ST_TRAV_CLOSEST - 1 + launch; }
         }
         // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
-        if (state == ST_SHADE && S.num_spheres == 0) end_sample();
+        if (state == ST_SHADE && num_spheres == 0) end_sample();
     }
     if constexpr (RNGMODE == 1) ln.rng = rng.n;
 }

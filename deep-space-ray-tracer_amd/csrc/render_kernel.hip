@@ -89,7 +89,7 @@ __device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2
 // Node-loop iterations per look at the loop's votes (1: +1.4 % time, 3: no better than 2; profiles/r03/ab_node_loop_unroll.jsonl).
 constexpr int kNodeUnroll = 2;
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false, bool LEAN = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -130,7 +130,17 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
             if (state < ST_TRAV_CLOSEST || state == ST_DONE) {
-                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH>(ln, args, c, flags);
+#ifdef DSRT_RELOAD_ARGS
+                // The pass reads its launch constants (camera, sun, sizes, scene pointers) from the kernel-argument segment WHERE IT USES THEM -- scalar loads through the
+                // constant cache -- instead of keeping ~60 scalar registers alive across the whole kernel for them: the pointer goes through an empty asm, so the
+                // compiler cannot hoist the loads out of the loop and spill their results to vector lanes (v_writelane / v_readlane are VALU instructions).
+                typedef const RenderArgs __attribute__((address_space(4)))* KernargPtr;
+                KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kp));
+                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH, LEAN>(ln, *(const RenderArgs*)kp, c, flags);
+#else
+                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH, LEAN>(ln, args, c, flags);
+#endif
             }
         }
 
@@ -177,6 +187,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                 wait_waste += kNodeUnroll * n_wait;
 #pragma unroll
                 for (int rep = 0; rep < kNodeUnroll; ++rep) {           // (body not re-indented: it is the iteration described above)
+                // (checked build) a reference in 0 .. kRefNone - 1 belongs to no class: such a lane would be counted as walking for ever.  Library-built records never hold one;
+                // a corrupted record or stack word might.
+                if (CHECKED && cur >= 0 && cur < kRefNone) { flags |= kFlagBadNodeRef; cur = kRefNone; }
                 if (COUNT) { c[C_NODE_SLOTS]++; if (cur < 0) c[C_IDLE_AT_LEAF]++; if (state < ST_TRAV_CLOSEST || (cur == kRefNone && state <= ST_TRAV_SHADOW)) c[C_IDLE_WAITING]++; if (state == ST_DONE) c[C_IDLE_DONE]++; }
 
                 // pop attempt: a postponed child is entered iff its entry distance is still in front of `closest`, which is
@@ -254,6 +267,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                 }                                                       // rep
             }
 
+            if (CHECKED && cur >= 0 && cur < kRefNone) { flags |= kFlagBadNodeRef; cur = kRefNone; }       // (a bad reference taken in the loop's last iteration)
             // rays that emptied their stack in the node loop: TRAV_CLOSEST -> SHADE, TRAV_SHADOW -> SHADOW_DONE (a lane in ST_TRAV_* without a node has just ended)
             if (cur == kRefNone && state >= ST_TRAV_CLOSEST && state <= ST_TRAV_SHADOW) state -= (ST_TRAV_CLOSEST - ST_SHADE);
 
@@ -351,15 +365,17 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
     if (flags) atomicOr(args.flags, flags);
 }
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE>
+// LEAN (path_machine.h): the instantiation for scenes of Lambertian triangles only, chosen by the host from what upload found in the scene.  Production builds only:
+// the counting and checked builds are the general code.
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool LEAN = false>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
-    render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false>(args);
+    render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false, false, LEAN>(args);
 }
 
 // Batch launch: many frames of one scene as one pool of work (path_machine.h, ST_FETCH).
-template <int RNGMODE>
+template <int RNGMODE, bool LEAN = false>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_batch_kernel(const RenderArgs args) {
-    render_body<8, false, false, true, RNGMODE, false, true>(args);
+    render_body<8, false, false, true, RNGMODE, false, true, LEAN>(args);
 }
 
 // Fills the count fields of the batch table (entries f and frames + f belong to frame f) from the sched words every frame's pre-pass
@@ -389,8 +405,9 @@ __global__ void dsrt_batch_table_kernel(BatchFrame* __restrict__ table, const ui
 
 // The probe launch of the pre-pass: the same body at a couple of samples per pixel, adding the rays every pixel needed to its
 // tile's entry of args.tile_work.  Its own kernel symbol, so that profiles keep it apart from the frame's launch.
+template <bool LEAN>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_probe_kernel(const RenderArgs args) {
-    render_body<8, false, false, true, 0, true>(args);
+    render_body<8, false, false, true, 0, true, false, LEAN>(args);
 }
 
 #ifndef DSRT_DEVICE_LIBM
@@ -682,9 +699,11 @@ __global__ void dsrt_resolve_kernel(const unsigned long long* __restrict__ sums,
 
 // ---- launchers (called from device_api.hip) -----------------------------------------------------------
 template <int K, int RNGMODE>
-static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
+static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool checked, bool anyhit, bool lean, hipStream_t stream) {
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
-    if (count) {
+    if (!count && !checked && lean) {
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE, true>), grid, block, 0, stream, a);
+    } else if (count) {
         if (anyhit) hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, true, RNGMODE>), grid, block, 0, stream, a);
         else        hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, false, RNGMODE>), grid, block, 0, stream, a);
     } else if (checked) {
@@ -695,9 +714,10 @@ static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool che
     return hipGetLastError();
 }
 
-hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, hipStream_t stream) {
-    if (rng_mode == 0) hipLaunchKernelGGL(dsrt_render_batch_kernel<0>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
-    else if (rng_mode == 1) hipLaunchKernelGGL(dsrt_render_batch_kernel<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+hipError_t launch_render_batch(const RenderArgs& a, int rng_mode, int blocks, bool lean, hipStream_t stream) {
+    const dim3 grid(blocks), block(64 * kWavesPerBlock);
+    if (rng_mode == 0) { if (lean) hipLaunchKernelGGL((dsrt_render_batch_kernel<0, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((dsrt_render_batch_kernel<0, false>), grid, block, 0, stream, a); }
+    else if (rng_mode == 1) { if (lean) hipLaunchKernelGGL((dsrt_render_batch_kernel<1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((dsrt_render_batch_kernel<1, false>), grid, block, 0, stream, a); }
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -711,15 +731,16 @@ hipError_t launch_batch_table(BatchFrame* table, const uint32_t* sched, uint32_t
 
 #endif
 
-hipError_t launch_probe(const RenderArgs& a, int blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(dsrt_probe_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+hipError_t launch_probe(const RenderArgs& a, int blocks, bool lean, hipStream_t stream) {
+    if (lean) hipLaunchKernelGGL(dsrt_probe_kernel<true>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
+    else hipLaunchKernelGGL(dsrt_probe_kernel<false>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, hipStream_t stream) {
+hipError_t launch_render(const RenderArgs& a, int lds_entries, int rng_mode, int blocks, bool count, bool checked, bool anyhit, bool lean, hipStream_t stream) {
     if (lds_entries != 8) return hipErrorInvalidValue;     // the only short-stack size built
-    if (rng_mode == 0) return launch_k<8, 0>(a, blocks, count, checked, anyhit, stream);
-    if (rng_mode == 1) return launch_k<8, 1>(a, blocks, count, checked, anyhit, stream);
+    if (rng_mode == 0) return launch_k<8, 0>(a, blocks, count, checked, anyhit, lean, stream);
+    if (rng_mode == 1) return launch_k<8, 1>(a, blocks, count, checked, anyhit, lean, stream);
     return hipErrorInvalidValue;
 }
 

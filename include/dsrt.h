@@ -35,7 +35,7 @@ const char* dsrt_last_error(void);
 /* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
  * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
  * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended;
- * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof).  dsrt_abi_version() returns the value the library was compiled with;
+ * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof, dsrt_dev_set_experiment, dsrt_selftest_poke_node_word).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
 #define DSRT_ABI_VERSION 7
 int dsrt_abi_version(void);
@@ -182,6 +182,12 @@ int dsrt_scene_upload_device(DsrtContext* ctx, const GPUScene* scene);
 /* Per-frame update: only camera and sun change between frames (src/main.cpp:399-405). */
 int dsrt_scene_set_camera_sun(DsrtContext* ctx, const GPUCamera* cam, const float sun_dir_model[3]);
 
+/* PARITY DOMAIN.  rng_mode 0 renders the reference's bytes (as the chosen math_mode defines them) for scenes whose coordinates keep the reference's own
+ * intermediates out of the subnormal and overflow ranges: for every box centre c, ray origin o and direction d the walk meets, |c - o| * |d| is zero or lies
+ * in [2^-100, 2^100] (metres-scale scenes are 20 orders of magnitude inside; tested from 1e-15 to 1e9 times the station's size, tests/test_gpu_parity.py
+ * ::test_scaled_scenes_match_the_oracle_bit_for_bit).  The kernel orders a node's children by 2 d where the reference compares d (render_kernel.hip): the
+ * same comparison exactly when no intermediate is subnormal or overflows.  Outside that range images are still valid renders, but near/far ties may
+ * resolve differently from the reference's. */
 typedef struct DsrtRenderDesc {
     int      width, height;         /* gpu_render_scene(scene, width, height)                     */
     int      spp;                   /* <1 -> 1, as src/gpu_render.cu:987-988                      */
@@ -203,14 +209,18 @@ typedef struct DsrtRenderDesc {
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, flags}.  None of them
                                        changes a pixel (tested against the oracle in every combination).  Flags, DSRT_TUNE_* below: the low
                                        two bits choose the pre-pass, the others switch one scheduling measure off each.  Any other bit is
-                                       refused (DSRT_ERR_INVALID): development switches are not part of this ABI -- they are read from the
-                                       environment variable DSRT_EXPERIMENT (csrc/device_api.hip) */
+                                       refused (DSRT_ERR_INVALID): development switches are not part of a render's description -- see
+                                       dsrt_dev_set_experiment below */
     int      math_mode;             /* where sinf / cosf / powf come from -- the three library functions of the path (src/gpu_render.cu:104-106, 157-158, 211,
                                        1019-1021).  0 (default): include/dsrt_detmath.h, built from correctly rounded operations only and shared with the CPU
                                        oracle: the image is a function of the inputs alone, the same on the GPU and on a CPU, and what every parity test
                                        against the oracle uses.  1: the device math library's own (what the reference's source gets when hipcc compiles it
-                                       for this GPU): the image is then, byte for byte, the one the reference's own kernel renders on the same GPU
-                                       (oracle/_ref/ref_gpu; tests/test_gpu_reference_kernel.py).  The two modes differ in the last place of those three
+                                       for this GPU WITH FLOATING-POINT CONTRACTION OFF): the image is then, byte for byte, the one the reference's own kernel
+                                       renders on the same GPU when built that way (oracle/_ref/ref_gpu: hipify-perl + hipcc -ffp-contract=off;
+                                       tests/golden/ref_gpu_images.json, tests/test_gpu_reference_fixtures.py).  hipcc's and nvcc's DEFAULT builds contract
+                                       a * b + c into one rounding; against such a build (or libdevice's math) either mode is a statistical match only
+                                       (oracle/_ref/ref_gpu_fma).  Mode 0 has the same standing against the reference's kernel built with dsrt_detmath.h in
+                                       place of those three functions (oracle/_ref/ref_gpu_detmath, tests/golden/ref_gpu_detmath_images.json).  The two modes differ in the last place of those three
                                        functions and therefore, one LCG stream per pixel being what it is, in individual pixels; statistically they are
                                        the same picture.  rng_mode and math_mode are independent */
 } DsrtRenderDesc;
@@ -331,6 +341,16 @@ int  dsrt_multi_uses_rccl(const DsrtMulti* m);
 /* Self-test: a one-rank RCCL communicator on `device` and one ncclGather of `bytes` bytes through it, checked.  All of the collective
  * path that can run on a single GPU. */
 int  dsrt_selftest_rccl_gather(int device, size_t bytes);
+
+/* Development switches (scheduling experiments of the A/B tools under tools/; the bits are listed in csrc/device_api.hip).  One process-wide word; its initial
+ * value is the environment variable DSRT_EXPERIMENT, read ONCE in the first dsrt_device_count / dsrt_ctx_create call -- never per render.  Undefined bits are
+ * refused (DSRT_ERR_INVALID) and a non-zero word is announced on stderr.  None changes an image byte; bit 27 replaces the optional FLOAT image of a counting
+ * build by timing words.  Not for production hosts. */
+int  dsrt_dev_set_experiment(uint32_t word);
+/* Test hook for the bounds-checked kernel build: overwrites 32-bit word `word_index` of the context's resident node-record array (device_layout.h: 16 words per
+ * record, words 12 and 13 are the child references) and returns the previous value in *old_value.  A checked render of a scene corrupted this way must come
+ * back with DSRT_ERR_DEVICE_FLAG, not hang. */
+int  dsrt_selftest_poke_node_word(DsrtContext* ctx, size_t word_index, uint32_t value, uint32_t* old_value);
 /* The scene (HOST pointers, reference layouts) is converted and made resident once per device. */
 int  dsrt_multi_scene_upload(DsrtMulti* m, const GPUScene* host_scene);
 /* ONE frame over all ranks: interleaved screen tiles (tile g -> rank g mod N), one ncclGather of the equal-sized compact

@@ -376,14 +376,16 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
     for flags in (64, 1 << 23, -(1 << 31)):
         with pytest.raises(dsrt.DsrtError):
             gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)))
-    # the development switches (env DSRT_EXPERIMENT, read per call) are scheduling only as well
+    # the development switches (dsrt_dev_set_experiment) are scheduling only as well; undefined bits are refused
     try:
         for xp in (64, 1 << 20):
-            os.environ["DSRT_EXPERIMENT"] = str(xp)
+            dsrt.set_experiment(xp)
             rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth), want_f32=True)
             assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), xp
     finally:
-        os.environ.pop("DSRT_EXPERIMENT", None)
+        dsrt.set_experiment(0)
+    with pytest.raises(dsrt.DsrtError):
+        dsrt.set_experiment(1 << 5)
     # rng_mode 1 sums samples as integers, so neither the scheduling switches nor sample stealing (+16 switches it off) may move a bit
     a, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
     for flags in (12, 16, 28, 1 + 16, 2):
@@ -391,11 +393,11 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
         assert np.array_equal(a, b), flags
     try:
         for xp in (1 << 31, 16 << 8, 1 << 28):                      # background pixels one item each; 16 slices per heavy pixel; 64-sample light items
-            os.environ["DSRT_EXPERIMENT"] = str(xp)
+            dsrt.set_experiment(xp)
             b, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
             assert np.array_equal(a, b), xp
     finally:
-        os.environ.pop("DSRT_EXPERIMENT", None)
+        dsrt.set_experiment(0)
 
 
 def test_cli_renders_pose_frames_like_the_library(dsrt, oracle, tmp_path):
@@ -993,7 +995,7 @@ def test_device_material_helpers_match_the_reference_known_answers(dsrt, gpu_ctx
     assert 16 < (b[1] != state).sum() < n                                     # both the drawing and the non-drawing branch occur
 
 
-@pytest.mark.parametrize("scale", [1.0 / 64.0, 4096.0, 1.0e9])
+@pytest.mark.parametrize("scale", [1.0e-15, 1.0 / 64.0, 4096.0, 1.0e9])
 def test_scaled_scenes_match_the_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, scale):
     """The node visit orders its two children by 2 d instead of the reference's d (fma(-2, o, lo + hi) = 2 (0.5 (lo + hi) - o), render_kernel.hip): an identity
     of IEEE arithmetic as long as no intermediate is subnormal or overflows.  The station at 1/64 of its size, 4096 times and a billion times its size (coordinates
@@ -1013,3 +1015,24 @@ def test_scaled_scenes_match_the_oracle_bit_for_bit(dsrt, gpu_ctx, oracle, scale
         assert getattr(st, key) == want_cnt[key], (key, getattr(st, key), want_cnt[key])
     if scale >= 1.0:
         assert int((rgb.max(axis=2) > 0).sum()) > 0.02 * W * H       # (at 1/64 the reference's absolute epsilons -- t_min 1e-3, |det| 1e-8 -- eat most hits: compared all the same)
+
+
+def test_checked_build_flags_a_corrupt_node_reference_instead_of_hanging(dsrt, gpu_ctx, oracle):
+    """A child reference in 0 .. 61 belongs to no class of device_layout.h (leaf < 0, none 62, pop 63, internal >= 64): a lane holding one would count as walking for
+    ever.  Upload validates every index, so only memory corruption can produce one -- which is what the bounds-checked build exists for: it must come back with
+    kFlagBadNodeRef (status bit 1), not run into the launch timeout.  The hook overwrites the root record's left child reference (word 12) in the resident scene."""
+    hs, scene, W, H, spp, depth = _scene(dsrt, "station_near")
+    gpu_ctx.upload(scene)
+    good, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, checked=1))
+    for bad in (5, 61, 0):
+        old = gpu_ctx.poke_node_word(12, bad)
+        try:
+            with pytest.raises(dsrt.DsrtError) as e:
+                gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, checked=1, tune=(0, 0, 0, 1)))      # (no pre-pass: its any-hit walk is an unchecked kernel)
+            assert e.value.code == -7 and "0x1" in str(e.value)             # DSRT_ERR_DEVICE_FLAG, kFlagBadNodeRef
+        finally:
+            gpu_ctx.poke_node_word(12, old)
+    again, _, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, checked=1))
+    assert np.array_equal(good, again)
+    want, _, _ = oracle.render(scene, W, H)
+    assert np.array_equal(good, want)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of render settings in ONE process on ONE box (development aid): each configuration `rng:switches[:loop knobs]` (the low six bits
-of `switches` are DsrtRenderDesc.tune[3], the DSRT_TUNE_* flags of include/dsrt.h; the rest goes into the environment variable DSRT_EXPERIMENT, the
+of `switches` are DsrtRenderDesc.tune[3], the DSRT_TUNE_* flags of include/dsrt.h; the rest goes to dsrt_dev_set_experiment, the
 library's development switches, csrc/device_api.hip) is rendered
 --reps times, round-robin, and the medians of the kernel times (HIP events) are printed.  Devices differ by a few per cent, so
 settings are only ever compared inside one run of this tool."""
@@ -54,11 +54,11 @@ def main():
     times = [[] for _ in descs]
     walls = [[] for _ in descs]
     for dsc, xp in descs:
-        os.environ["DSRT_EXPERIMENT"] = str(xp)                                   # read by the library at every render call
+        d.set_experiment(xp)
         ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True)           # warm-up
     for _ in range(a.reps):
         for i, (dsc, xp) in enumerate(descs):
-            os.environ["DSRT_EXPERIMENT"] = str(xp)
+            d.set_experiment(xp)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             times[i].append(ctx.render(dsc, buf.data_ptr(), stream=stream, want_stats=True).kernel_ms)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: when did every pixel's chain of samples start and end?  (rng_mode 0: a pixel is one serial chain, and the frame ends
-with its last chain.)  Renders one frame with the counting build and bit 27 of the development switches (env DSRT_EXPERIMENT), which makes the kernel write (fetch time, end time,
+with its last chain.)  Renders one frame with the counting build and bit 27 of the development switches (dsrt_dev_set_experiment), which makes the kernel write (fetch time, end time,
 wave) per pixel into the float image, and prints how the frame's end is composed."""
 import argparse
 import json
@@ -40,7 +40,7 @@ def main():
     ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
     stream = torch.cuda.current_stream().cuda_stream
     n = a.shards
-    os.environ["DSRT_EXPERIMENT"] = str(1 << 27)                  # the float image receives (fetch time, end time, wave) per pixel
+    d.set_experiment(1 << 27)                 # the float image receives (fetch time, end time, wave) per pixel
     desc = d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, collect_counters=1, tune=(0, 0, 0, a.tune3 & 63))
     lay = d.shard_layout(desc)
     npx = lay["rgb8_bytes_padded"] // 3 if n > 1 else W * H
