@@ -608,7 +608,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 10;            // (16 until the node loop looked at its votes every other iteration: profiles/r03/ab_loop_knobs_after_unroll.jsonl)
-    a.deal_leaves = (xp & 128u) ? 0 : 1;                        // (development switch 128: the leaf pass without dealing, for A/B runs)
+    a.deal_leaves = (xp & 128u) ? 0 : 1;
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).

@@ -130,17 +130,14 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
             if (COUNT) { c[C_ADV_SLOTS]++; if (state < ST_TRAV_CLOSEST) c[C_ADV_ACTIVE]++; }
             // idle lanes go through the step too: that is where they pick up shadow rays
             if (state < ST_TRAV_CLOSEST || state == ST_DONE) {
-#ifdef DSRT_RELOAD_ARGS
                 // The pass reads its launch constants (camera, sun, sizes, scene pointers) from the kernel-argument segment WHERE IT USES THEM -- scalar loads through the
                 // constant cache -- instead of keeping ~60 scalar registers alive across the whole kernel for them: the pointer goes through an empty asm, so the
-                // compiler cannot hoist the loads out of the loop and spill their results to vector lanes (v_writelane / v_readlane are VALU instructions).
+                // compiler cannot hoist the loads out of the loop and then spill their results to vector lanes (105 spilled scalars, 170 v_readlane / v_writelane in this
+                // pass, before; none now, and 112 VGPRs instead of 128.  Time: unchanged within the noise, profiles/r04/ab_kernarg_reload_*.jsonl).
                 typedef const RenderArgs __attribute__((address_space(4)))* KernargPtr;
                 KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kp));
                 advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH, LEAN>(ln, *(const RenderArgs*)kp, c, flags);
-#else
-                advance_step<COUNT, CHECKED, ANYHIT, RNGMODE, PROBE, BATCH, LEAN>(ln, args, c, flags);
-#endif
             }
         }
 

@@ -61,6 +61,10 @@ static inline V3 ray_at(const Ray* r, float t) {
 typedef struct {                                       /* HitRecord :264-279 */
     float t; V3 p; V3 normal; int mat_id; int tri_tex_id; int tri_index; float u, v; int front_face;
 } Hit;
+#ifdef DSRT_ORACLE_RAY_HOOK
+/* experiment builds that #include this file (sah_certificate_probe.c) see every BVH answer of the reference walk: scene_hit below calls this */
+static void DSRT_ORACLE_RAY_HOOK(const GPUScene* s, const Ray* ray, float t_min, float t_max, int bvh_hit, const Hit* rec);
+#endif
 static inline void set_face_normal(Hit* h, const Ray* r, V3 outward) {
     h->front_face = (dot(r->dir, outward) < 0.0f);
     h->normal = h->front_face ? outward : scale(outward, -1.0f);
@@ -322,7 +326,12 @@ static int scene_hit(const GPUScene* s, const Ray* ray, float t_min, float t_max
     int hit_any = 0;
     float closest = t_max;
     Hit tri_rec;
-    if (bvh_hit_closest(s, ray, t_min, closest, &tri_rec, c) > 0) {
+    const int bvh_hit = bvh_hit_closest(s, ray, t_min, closest, &tri_rec, c) > 0;
+#ifdef DSRT_ORACLE_RAY_HOOK
+    /* (experiment builds only, e.g. sah_certificate_probe.c, which #includes this file: every BVH answer of the reference walk is shown to the experiment) */
+    DSRT_ORACLE_RAY_HOOK(s, ray, t_min, t_max, bvh_hit, &tri_rec);
+#endif
+    if (bvh_hit) {
         hit_any = 1;
         closest = tri_rec.t;
         best = tri_rec;
