@@ -58,7 +58,7 @@ VALU_PEAK_CYCLES_PER_WAVE_INSTR = 2.0   # /opt/skills/guides/MI355X_MICROARCH.md
 # shares of the issued stream, node loop 0.57 / leaf pass 0.21 / advance 0.22 (trip counts of the counting build x VALU per trip against SQ_INSTS_VALU;
 # profiles/r03/isa_mix.txt): share of simple-rate, half-rate and quarter-rate instructions
 KERNEL_VALU_CLASS_SHARES = {"simple": 0.26, "half": 0.67, "quarter": 0.07}
-RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0>"
+RENDER_KERNEL = "dsrt_render_kernel<8, false, false, true, 0"       # (prefix: the LEAN instantiation appends a template argument)
 
 
 def algorithmic_bytes(st, pixels):

@@ -275,6 +275,15 @@ class Context:
         other._h, other.device = h, self.device
         return other
 
+    def set_certified_tree(self, on=True):
+        """The next upload also builds the certified second tree (include/dsrt.h): rays walk a SAH tree, the kernel certifies every answer against the reference tree."""
+        _check(lib.dsrt_ctx_set_certified_tree(self._h, 1 if on else 0), "dsrt_ctx_set_certified_tree")
+        return self
+
+    @property
+    def has_certified_tree(self):
+        return bool(lib.dsrt_ctx_has_certified_tree(self._h))
+
     def upload(self, scene_host_view):
         _check(lib.dsrt_scene_upload(self._h, C.byref(scene_host_view)), "dsrt_scene_upload")
 

@@ -88,8 +88,8 @@ class DsrtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("waves_launched", C.c_int), ("device_flags", C.c_uint32), ("lds_stack_entries", C.c_int)] + \
                [(n, C.c_uint64) for n in ("samples", "rays", "primary_hits", "box_fetches", "nodes_entered", "internal_entered", "tri_tests",
                                           "hit_updates", "sphere_tests", "shaded_hits", "tex_fetches", "stack_spills", "max_stack",
-                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12", "tiles_total", "tiles_culled", "wave_ticks")] + \
-               [(n, C.c_float) for n in ("heavy_queue_empty_ms", "light_queue_empty_ms", "last_wave_exit_ms")]
+                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12", "tiles_total", "tiles_culled", "wave_ticks", "certificate_fallbacks")] + \
+               [(n, C.c_float) for n in ("heavy_queue_empty_ms", "light_queue_empty_ms", "last_wave_exit_ms")] + [("certified_tree_used", C.c_int)]
 
 
 # numpy record layouts of the reference arrays (for dumping / comparing with goldens)
@@ -106,7 +106,7 @@ assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.ite
 ABI_VERSION = 7
 
 EXPORTS = [
-    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word",
+    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word", "dsrt_ctx_set_certified_tree", "dsrt_ctx_has_certified_tree",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_add_texture_file", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
@@ -174,6 +174,8 @@ def load():
     sig("dsrt_ctx_destroy", None, [vp])
     sig("dsrt_ctx_clone", C.c_int, [vp, P(vp)])
     sig("dsrt_ctx_device", C.c_int, [vp])
+    sig("dsrt_ctx_set_certified_tree", C.c_int, [vp, C.c_int])
+    sig("dsrt_ctx_has_certified_tree", C.c_int, [vp])
     sig("dsrt_multi_create", C.c_int, [P(C.c_int), C.c_int, C.c_int, P(vp)])
     sig("dsrt_multi_destroy", None, [vp])
     sig("dsrt_multi_count", C.c_int, [vp])

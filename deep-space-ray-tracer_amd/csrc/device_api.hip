@@ -95,7 +95,7 @@ struct DevBuf {
 
 // The scene in traversal layout, owning its device memory.
 struct PackedScene {
-    DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, materials;
+    DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, tri_cert, materials;
     DevBuf<uint8_t> pair_depth;
     DevBuf<int2> big_leaves;
     DevBuf<GPUSphere> spheres;
@@ -105,6 +105,8 @@ struct PackedScene {
     GPUCamera camera{};
     DsrtF3 sun_dir{}, sun_radiance{};
     int sun_enabled = 0;
+    bool has_second_tree = false;   // the certified second tree is resident (pack_scene)
+    float scene_extent = 0.0f, scene_centre[3] = {0, 0, 0};
     bool lean = false;              // no spheres, no textures, Lambertian materials only: the production launches use the kernels' LEAN instantiation (path_machine.h)
     bool valid = false;
 };
@@ -112,9 +114,112 @@ struct PackedScene {
 float4 as_f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 float bits(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 
-// Host-side conversion of reference-layout arrays into the traversal layout.  Validates every index the kernel
-// will follow, so the fast (unchecked) kernel build never sees an out-of-range reference.
-int pack_scene(const GPUScene& h, PackedScene& out) {
+// What packing one tree into the shared arrays yields.
+struct PackedTree { int root_ref = kRefNone; int stack_need = 0; float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
+
+// The arrays both trees are appended to (device_layout.h).  References are absolute: an internal reference is its record's index in `pairs` + kRefBias, a leaf
+// reference carries the index of its first record in `isect`; `shade` / `uv` / `cert` grow in step with `isect` (two slots per pair record).
+struct PackArrays {
+    std::vector<float4> pairs, isect, shade, uv, cert;
+    std::vector<int> depth_of_all;                                       // depth of every record of `pairs` (the counting build's histogram reads it)
+    std::vector<int2> big;
+};
+
+// Appends the tree (nodes, tri_indices) over the scene's triangles.  Validates every index the kernel will follow, so the fast (unchecked) kernel build never sees
+// an out-of-range reference.  `cert_boxes` (null, or 6 floats per TRIANGLE): appended per slot to arr.cert -- the certified second tree's records.
+int pack_tree(const GPUScene& h, const GPUBVHNode* nodes, int M, const int* tri_indices, int n_indexed, bool textured, const float* cert_boxes, PackArrays& arr, PackedTree& out) {
+    const int N = h.num_triangles;
+    for (int i = 0; i < n_indexed; ++i) if (tri_indices[i] < 0 || tri_indices[i] >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
+    // internal node -> slot in `pairs`, assigned in a depth-first walk from the root (also detects cycles / sharing)
+    const int base = (int)(arr.pairs.size() / 4);
+    std::vector<int> slot_of(M, -1);
+    std::vector<char> seen(M, 0);
+    struct Item { int node; int internal_above; };
+    std::vector<Item> todo{{0, 0}};
+    int stack_need = 0;
+    std::vector<int> order;                                          // internal nodes in visiting order
+    std::vector<int> depth_of;                                       // ... and their depth (root = 0)
+    while (!todo.empty()) {
+        Item it = todo.back(); todo.pop_back();
+        if (it.node < 0 || it.node >= M) { set_error("BVH child index out of range"); return DSRT_ERR_INVALID; }
+        if (seen[it.node]) { set_error("BVH is not a tree (node reached twice)"); return DSRT_ERR_INVALID; }
+        seen[it.node] = 1;
+        const GPUBVHNode& n = nodes[it.node];
+        if (n.tri_count > 0) {
+            if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > n_indexed) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
+            if (it.internal_above > stack_need) stack_need = it.internal_above;
+        } else {
+            slot_of[it.node] = (int)order.size();
+            order.push_back(it.node);
+            depth_of.push_back(it.internal_above);
+            todo.push_back({n.right, it.internal_above + 1});
+            todo.push_back({n.left, it.internal_above + 1});
+        }
+    }
+    if (stack_need > 64) { set_error("BVH needs a traversal stack deeper than the reference's 64 entries"); return DSRT_ERR_BVH_DEPTH; }
+    // Triangle storage: every leaf gets ceil(count / 2) pair records of its own, filled in tri_indices order.
+    auto emit_leaf = [&](const GPUBVHNode& n) -> int {
+        const int first_pair = (int)(arr.isect.size() / 5);
+        for (int i = 0; i < n.tri_count; i += 2) {
+            float q[2][9] = {{0}};
+            for (int w = 0; w < 2; ++w) {
+                const bool real = i + w < n.tri_count;
+                const int src = real ? tri_indices[n.tri_offset + i + w] : -1;
+                float4 s0 = as_f4(0, 0, 0, 0), s1 = s0, s2 = as_f4(0, bits(0), bits(-1), bits(-1)), u0 = s0, u1 = s0, c0 = s0, c1 = s0;
+                if (real) {
+                    const GPUTriangle& t = h.triangles[src];
+                    const float v[9] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z, t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+                    std::memcpy(q[w], v, sizeof v);
+                    s0 = as_f4(t.n0.x, t.n0.y, t.n0.z, t.n1.x);
+                    s1 = as_f4(t.n1.y, t.n1.z, t.n2.x, t.n2.y);
+                    s2 = as_f4(t.n2.z, bits(t.material_id), bits(t.albedo_tex), bits(src));
+                    u0 = as_f4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
+                    u1 = as_f4(t.uv2.x, t.uv2.y, 0.0f, 0.0f);
+                    if (cert_boxes) { const float* cb = cert_boxes + 6 * (size_t)src; c0 = as_f4(cb[0], cb[1], cb[2], cb[3]); c1 = as_f4(cb[4], cb[5], 0.0f, 0.0f); }
+                }
+                arr.shade.push_back(s0); arr.shade.push_back(s1); arr.shade.push_back(s2);
+                if (textured) { arr.uv.push_back(u0); arr.uv.push_back(u1); }
+                if (cert_boxes) { arr.cert.push_back(c0); arr.cert.push_back(c1); }
+            }
+            arr.isect.push_back(as_f4(q[0][0], q[1][0], q[0][1], q[1][1]));
+            arr.isect.push_back(as_f4(q[0][2], q[1][2], q[0][3], q[1][3]));
+            arr.isect.push_back(as_f4(q[0][4], q[1][4], q[0][5], q[1][5]));
+            arr.isect.push_back(as_f4(q[0][6], q[1][6], q[0][7], q[1][7]));
+            arr.isect.push_back(as_f4(q[0][8], q[1][8], 0.0f, 0.0f));
+        }
+        return first_pair;
+    };
+    auto ref_of = [&](int node) -> int {
+        const GPUBVHNode& n = nodes[node];
+        if (n.tri_count <= 0) return base + slot_of[node] + kRefBias;
+        const int first_pair = emit_leaf(n);
+        if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, first_pair);
+        arr.big.push_back(make_int2(first_pair, n.tri_count));
+        return make_leaf_ref(7, (int)arr.big.size() - 1);
+    };
+    arr.pairs.resize(((size_t)base + order.size()) * 4);
+    for (size_t s = 0; s < order.size(); ++s) {
+        const GPUBVHNode& n = nodes[order[s]];
+        const GPUBVHNode& l = nodes[n.left];
+        const GPUBVHNode& r = nodes[n.right];
+        float4* rec = arr.pairs.data() + 4 * ((size_t)base + s);
+        rec[0] = as_f4(l.bbox_min.x, r.bbox_min.x, l.bbox_max.x, r.bbox_max.x);
+        rec[1] = as_f4(l.bbox_min.y, r.bbox_min.y, l.bbox_max.y, r.bbox_max.y);
+        rec[2] = as_f4(l.bbox_min.z, r.bbox_min.z, l.bbox_max.z, r.bbox_max.z);
+        const int ref_left = ref_of(n.left), ref_right = ref_of(n.right);          // in this order: leaf records follow the walk
+        rec[3] = as_f4(bits(ref_left), bits(ref_right), l.bbox_min.x + l.bbox_max.x, r.bbox_min.x + r.bbox_max.x);   // the x sums of the ordering test, in float as the kernel would form them
+    }
+    arr.depth_of_all.insert(arr.depth_of_all.end(), depth_of.begin(), depth_of.end());
+    const GPUBVHNode& root = nodes[0];
+    out.lo[0] = root.bbox_min.x; out.lo[1] = root.bbox_min.y; out.lo[2] = root.bbox_min.z;
+    out.hi[0] = root.bbox_max.x; out.hi[1] = root.bbox_max.y; out.hi[2] = root.bbox_max.z;
+    out.root_ref = ref_of(0);
+    out.stack_need = stack_need;
+    return DSRT_OK;
+}
+
+// Host-side conversion of reference-layout arrays into the traversal layout.  `second_tree`: also build and pack the certified second tree (below).
+int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
     const int N = h.num_triangles, M = h.num_bvh_nodes;
     if (N < 0 || M < 0 || h.num_spheres < 0 || h.num_materials < 0 || h.num_textures < 0 || h.texture_pool_floats < 0) {
         set_error("scene has a negative count"); return DSRT_ERR_INVALID;
@@ -125,103 +230,76 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
     for (int i = 0; i < N; ++i) if (h.triangles[i].material_id < 0 || h.triangles[i].material_id >= h.num_materials) { set_error("triangle material id out of range"); return DSRT_ERR_INVALID; }
     for (int i = 0; i < h.num_spheres; ++i) if (h.spheres[i].material_id < 0 || h.spheres[i].material_id >= h.num_materials) { set_error("sphere material id out of range"); return DSRT_ERR_INVALID; }
 
-    std::vector<float4> pairs, isect, shade, uv, mats;
-    std::vector<int> depth_of_all;                                       // depth of every record of `pairs` (the counting build's histogram reads it)
-    std::vector<int2> big;
+    PackArrays arr;
+    std::vector<float4> mats;
     DeviceScene& v = out.view;
     std::memset(&v, 0, sizeof v);
     v.root_ref = kRefNone;
+    v.accel_root_ref = kRefNone;
+    out.has_second_tree = false;
 
     if (has_bvh) {
-        for (int i = 0; i < N; ++i) if (h.tri_indices[i] < 0 || h.tri_indices[i] >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
-        // internal node -> slot in `pairs`, assigned in a depth-first walk from the root (also detects cycles / sharing)
-        std::vector<int> slot_of(M, -1);
-        std::vector<char> seen(M, 0);
-        struct Item { int node; int internal_above; };
-        std::vector<Item> todo{{0, 0}};
-        int stack_need = 0;
-        std::vector<int> order;                                          // internal nodes in visiting order
-        std::vector<int> depth_of;                                       // ... and their depth (root = 0)
-        while (!todo.empty()) {
-            Item it = todo.back(); todo.pop_back();
-            if (it.node < 0 || it.node >= M) { set_error("BVH child index out of range"); return DSRT_ERR_INVALID; }
-            if (seen[it.node]) { set_error("BVH is not a tree (node reached twice)"); return DSRT_ERR_INVALID; }
-            seen[it.node] = 1;
-            const GPUBVHNode& n = h.bvh_nodes[it.node];
-            if (n.tri_count > 0) {
-                if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
-                if (it.internal_above > stack_need) stack_need = it.internal_above;
-            } else {
-                slot_of[it.node] = (int)order.size();
-                order.push_back(it.node);
-                depth_of.push_back(it.internal_above);
-                todo.push_back({n.right, it.internal_above + 1});
-                todo.push_back({n.left, it.internal_above + 1});
-            }
-        }
-        if (stack_need > 64) { set_error("BVH needs a traversal stack deeper than the reference's 64 entries"); return DSRT_ERR_BVH_DEPTH; }
-        // Triangle storage: every leaf gets ceil(count / 2) pair records of its own, filled in tri_indices order.
         const bool textured = h.num_textures > 0 && h.textures && h.texture_pool;
-        auto emit_leaf = [&](const GPUBVHNode& n) -> int {
-            const int first_pair = (int)(isect.size() / 5);
-            for (int i = 0; i < n.tri_count; i += 2) {
-                float q[2][9] = {{0}};
-                for (int w = 0; w < 2; ++w) {
-                    const bool real = i + w < n.tri_count;
-                    const int src = real ? h.tri_indices[n.tri_offset + i + w] : -1;
-                    float4 s0 = as_f4(0, 0, 0, 0), s1 = s0, s2 = as_f4(0, bits(0), bits(-1), bits(-1)), u0 = s0, u1 = s0;
-                    if (real) {
-                        const GPUTriangle& t = h.triangles[src];
-                        const float v[9] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z, t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
-                        std::memcpy(q[w], v, sizeof v);
-                        s0 = as_f4(t.n0.x, t.n0.y, t.n0.z, t.n1.x);
-                        s1 = as_f4(t.n1.y, t.n1.z, t.n2.x, t.n2.y);
-                        s2 = as_f4(t.n2.z, bits(t.material_id), bits(t.albedo_tex), bits(src));
-                        u0 = as_f4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
-                        u1 = as_f4(t.uv2.x, t.uv2.y, 0.0f, 0.0f);
-                    }
-                    shade.push_back(s0); shade.push_back(s1); shade.push_back(s2);
-                    if (textured) { uv.push_back(u0); uv.push_back(u1); }
+        arr.isect.reserve(((size_t)N / 2 + (size_t)M / 2 + 1) * 5 * (second_tree ? 2 : 1));
+        arr.shade.reserve(((size_t)N + (size_t)M / 2 + 2) * 3 * (second_tree ? 2 : 1));
+        PackedTree ref_tree, acc_tree;
+        if (second_tree && N > 0) {
+            // THE CERTIFIED SECOND TREE.  A ray's answer on the reference's tree is the accepted triangle of smallest t, except where it depends on the reference's own
+            // boxes or order; path_machine.h checks, per ray, the three conditions under which it provably is (the certificate) and re-walks the reference tree
+            // otherwise.  What the check needs from here: (a) the triangles the reference walk can never reach -- a zero-thickness box on their root-to-leaf path:
+            // bbox_hit's `t_max <= t_min` holds with equality, src/gpu_render.cu:312 -- are left OUT of the second tree; (b) every triangle's leaf box ON THE
+            // REFERENCE TREE rides with its slot (tri_cert); (c) the second tree's boxes are widened by 2^-16 of the scene's extent, so that no rounding of the slab
+            // arithmetic makes a ray miss the box of a triangle it hits (ray origins up to 30 extents away: render_impl checks the camera).
+            std::vector<uint8_t> unreachable((size_t)N, 0);
+            std::vector<float> leaf_box((size_t)N * 6, 0.0f);
+            {
+                struct Walk { int node; bool dead; };
+                std::vector<Walk> todo{{0, false}};
+                std::vector<char> seen((size_t)M, 0);
+                while (!todo.empty()) {
+                    Walk w = todo.back(); todo.pop_back();
+                    if (w.node < 0 || w.node >= M || seen[(size_t)w.node]) { set_error("BVH is not a tree"); return DSRT_ERR_INVALID; }
+                    seen[(size_t)w.node] = 1;
+                    const GPUBVHNode& n = h.bvh_nodes[w.node];
+                    const bool dead = w.dead || n.bbox_min.x == n.bbox_max.x || n.bbox_min.y == n.bbox_max.y || n.bbox_min.z == n.bbox_max.z;
+                    if (n.tri_count > 0) {
+                        if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
+                        for (int i = 0; i < n.tri_count; ++i) {
+                            const int t = h.tri_indices[n.tri_offset + i];
+                            if (t < 0 || t >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
+                            float* b = &leaf_box[6 * (size_t)t];
+                            b[0] = n.bbox_min.x; b[1] = n.bbox_min.y; b[2] = n.bbox_min.z; b[3] = n.bbox_max.x; b[4] = n.bbox_max.y; b[5] = n.bbox_max.z;
+                            if (dead) unreachable[(size_t)t] = 1;
+                        }
+                    } else { todo.push_back({n.left, dead}); todo.push_back({n.right, dead}); }
                 }
-                isect.push_back(as_f4(q[0][0], q[1][0], q[0][1], q[1][1]));
-                isect.push_back(as_f4(q[0][2], q[1][2], q[0][3], q[1][3]));
-                isect.push_back(as_f4(q[0][4], q[1][4], q[0][5], q[1][5]));
-                isect.push_back(as_f4(q[0][6], q[1][6], q[0][7], q[1][7]));
-                isect.push_back(as_f4(q[0][8], q[1][8], 0.0f, 0.0f));
             }
-            return first_pair;
-        };
-        isect.reserve(((size_t)N / 2 + (size_t)M / 2 + 1) * 5);
-        shade.reserve(((size_t)N + (size_t)M / 2 + 2) * 3);
-        auto ref_of = [&](int node) -> int {
-            const GPUBVHNode& n = h.bvh_nodes[node];
-            if (n.tri_count <= 0) return slot_of[node] + kRefBias;
-            const int first_pair = emit_leaf(n);
-            if (n.tri_count <= 7) return make_leaf_ref(n.tri_count - 1, first_pair);
-            big.push_back(make_int2(first_pair, n.tri_count));
-            return make_leaf_ref(7, (int)big.size() - 1);
-        };
-        pairs.resize(order.size() * 4);
-        for (size_t s = 0; s < order.size(); ++s) {
-            const GPUBVHNode& n = h.bvh_nodes[order[s]];
-            const GPUBVHNode& l = h.bvh_nodes[n.left];
-            const GPUBVHNode& r = h.bvh_nodes[n.right];
-            pairs[4 * s + 0] = as_f4(l.bbox_min.x, r.bbox_min.x, l.bbox_max.x, r.bbox_max.x);
-            pairs[4 * s + 1] = as_f4(l.bbox_min.y, r.bbox_min.y, l.bbox_max.y, r.bbox_max.y);
-            pairs[4 * s + 2] = as_f4(l.bbox_min.z, r.bbox_min.z, l.bbox_max.z, r.bbox_max.z);
-            const int ref_left = ref_of(n.left), ref_right = ref_of(n.right);          // in this order: leaf records follow the walk
-            pairs[4 * s + 3] = as_f4(bits(ref_left), bits(ref_right), l.bbox_min.x + l.bbox_max.x, r.bbox_min.x + r.bbox_max.x);   // the x sums of the ordering test, in float as the kernel would form them
+            const GPUBVHNode& root = h.bvh_nodes[0];
+            const float extent = std::fmax(std::fmax(root.bbox_max.x - root.bbox_min.x, root.bbox_max.y - root.bbox_min.y), root.bbox_max.z - root.bbox_min.z);
+            std::vector<GPUBVHNode> nodes2;
+            std::vector<int> order2;
+            int height2 = 0;
+            int rc = build_sah_tree(h.triangles, (size_t)N, extent > 0.0f ? extent * (1.0f / 65536.0f) : 1.0e-6f, unreachable.data(), nodes2, order2, height2);
+            if (rc != DSRT_OK) return rc;
+            if (!nodes2.empty()) {
+                if ((rc = pack_tree(h, nodes2.data(), (int)nodes2.size(), order2.data(), (int)order2.size(), textured, leaf_box.data(), arr, acc_tree))) return rc;
+                out.has_second_tree = true;
+                out.scene_extent = extent;
+                for (int a = 0; a < 3; ++a) out.scene_centre[a] = 0.5f * ((&root.bbox_min.x)[a] + (&root.bbox_max.x)[a]);
+            }
         }
-        depth_of_all = depth_of;
-        const GPUBVHNode& root = h.bvh_nodes[0];
-        v.root_lo[0] = root.bbox_min.x; v.root_lo[1] = root.bbox_min.y; v.root_lo[2] = root.bbox_min.z;
-        v.root_hi[0] = root.bbox_max.x; v.root_hi[1] = root.bbox_max.y; v.root_hi[2] = root.bbox_max.z;
-        v.root_ref = ref_of(0);
-        v.stack_need = stack_need;
+        int rc = pack_tree(h, h.bvh_nodes, M, h.tri_indices, N, textured, nullptr, arr, ref_tree);
+        if (rc) return rc;
+        for (int a = 0; a < 3; ++a) { v.root_lo[a] = ref_tree.lo[a]; v.root_hi[a] = ref_tree.hi[a]; v.accel_root_lo[a] = acc_tree.lo[a]; v.accel_root_hi[a] = acc_tree.hi[a]; }
+        v.root_ref = ref_tree.root_ref;
+        v.accel_root_ref = out.has_second_tree ? acc_tree.root_ref : kRefNone;
+        v.stack_need = std::max(ref_tree.stack_need, acc_tree.stack_need);
 
-        if (isect.size() / 5 > (size_t)(1 << 28)) { set_error("too many triangle pair records"); return DSRT_ERR_INVALID; }
-        if (pairs.size() / 4 + kRefBias >= ((size_t)1 << 26)) { set_error("more than 2^26 - 64 internal BVH nodes (the kernel addresses node records by a 32-bit byte offset)"); return DSRT_ERR_INVALID; }
+        if (arr.isect.size() / 5 > (size_t)(1 << 28)) { set_error("too many triangle pair records"); return DSRT_ERR_INVALID; }
+        if (arr.pairs.size() / 4 + kRefBias >= ((size_t)1 << 26)) { set_error("more than 2^26 - 64 internal BVH nodes (the kernel addresses node records by a 32-bit byte offset)"); return DSRT_ERR_INVALID; }
     }
+    std::vector<float4>& pairs = arr.pairs; std::vector<float4>& isect = arr.isect; std::vector<float4>& shade = arr.shade; std::vector<float4>& uv = arr.uv;
+    std::vector<int2>& big = arr.big; std::vector<int>& depth_of_all = arr.depth_of_all;
     mats.resize((size_t)h.num_materials * 3);
     for (int i = 0; i < h.num_materials; ++i) {
         const GPUMaterial& m = h.materials[i];
@@ -248,7 +326,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         if ((rc = out.pair_depth.upload(depth_bytes))) return rc;
     }
     if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_pairs.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
-        (rc = out.tri_uv.upload(uv)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
+        (rc = out.tri_uv.upload(uv)) || (rc = out.tri_cert.upload(arr.cert)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
     std::vector<GPUSphere> sph(h.spheres, h.spheres + h.num_spheres);
     if ((rc = out.spheres.upload(sph))) return rc;
     if (h.num_textures > 0 && h.textures && h.texture_pool) {
@@ -257,7 +335,7 @@ int pack_scene(const GPUScene& h, PackedScene& out) {
         if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
     } else { out.tex_headers.reset(); out.tex_pool.reset(); }
 
-    v.pair_depth = out.pair_depth.p; v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p;
+    v.pair_depth = out.pair_depth.p; v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p; v.tri_cert = out.tri_cert.p;
     v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
     v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
     v.num_pairs = (int)(pairs.size() / 4); v.num_tri_pairs = (int)(isect.size() / 5); v.num_big_leaves = (int)big.size();
@@ -282,6 +360,7 @@ struct DsrtContext {
     GPUCamera camera{};
     DsrtF3 sun_dir{}, sun_radiance{};
     int sun_enabled = 0;
+    bool want_second_tree = false;  // dsrt_ctx_set_certified_tree / DSRT_CERTIFIED_TREE: the next upload also builds and packs the certified second tree
     DevBuf<uint32_t> ctrl;          // [0] queue, [1] flags, then counters (uint64 x kNumCounters) at byte 16
     DevBuf<uint2> spill;
     DevBuf<uint32_t> tile_cost, tile_order, tile_work, tile_tmp, probe_queue;
@@ -300,7 +379,7 @@ namespace {
 int install_scene(DsrtContext* ctx, const GPUScene& host_layout) {
     auto fresh = std::make_shared<PackedScene>();
     ctx->scene.reset();
-    const int rc = pack_scene(host_layout, *fresh);
+    const int rc = pack_scene(host_layout, *fresh, ctx->want_second_tree);
     if (rc) return rc;
     ctx->scene = std::move(fresh);
     ctx->camera = ctx->scene->camera;
@@ -401,6 +480,7 @@ int dsrt_ctx_create(int device, DsrtContext** out) {
     auto* ctx = new DsrtContext();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char* e = std::getenv("DSRT_CERTIFIED_TREE")) ctx->want_second_tree = e[0] == '1';
     int rc = ctx->ctrl.alloc(kCtrlWords);
     if (rc) { delete ctx; return rc; }
     if (!hip_ok(hipEventCreate(&ctx->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&ctx->ev1), "hipEventCreate") ||
@@ -414,12 +494,21 @@ int dsrt_ctx_clone(const DsrtContext* src, DsrtContext** out) {
     const int rc = dsrt_ctx_create(src->device, out);
     if (rc) return rc;
     (*out)->scene = src->scene;                    // shared, read-only on the device
+    (*out)->want_second_tree = src->want_second_tree;
     (*out)->camera = src->camera;
     (*out)->sun_dir = src->sun_dir; (*out)->sun_radiance = src->sun_radiance; (*out)->sun_enabled = src->sun_enabled;
     return DSRT_OK;
 }
 
 int dsrt_ctx_device(const DsrtContext* ctx) { return ctx ? ctx->device : -1; }
+
+int dsrt_ctx_set_certified_tree(DsrtContext* ctx, int on) {
+    if (!ctx) { set_error("dsrt_ctx_set_certified_tree: null context"); return DSRT_ERR_INVALID; }
+    ctx->want_second_tree = on != 0;
+    return DSRT_OK;
+}
+
+int dsrt_ctx_has_certified_tree(const DsrtContext* ctx) { return ctx && ctx->scene && ctx->scene->valid && ctx->scene->has_second_tree ? 1 : 0; }
 
 void dsrt_ctx_destroy(DsrtContext* ctx) {
     if (!ctx) return;
@@ -609,6 +698,20 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 10;            // (16 until the node loop looked at its votes every other iteration: profiles/r03/ab_loop_knobs_after_unroll.jsonl)
     a.deal_leaves = (xp & 128u) ? 0 : 1;
+    // The certified second tree (pack_scene): used when it is resident, the host has not asked for the plain reference walk, and every camera of the launch is within
+    // 30 scene extents of the scene's centre (the widening of the second tree's boxes covers the rounding of (box - origin) up to there; bounce and shadow rays start
+    // on the geometry).  Otherwise every ray walks the reference tree, as without the option.
+    a.accel = 0;
+    if (sc.has_second_tree && !(flags & DSRT_TUNE_REFERENCE_WALK)) {
+        auto near_enough = [&](const DsrtF3& o) {
+            const double dx = (double)o.x - sc.scene_centre[0], dy = (double)o.y - sc.scene_centre[1], dz = (double)o.z - sc.scene_centre[2];
+            return std::sqrt(dx * dx + dy * dy + dz * dz) <= 30.0 * (double)sc.scene_extent;
+        };
+        bool ok = true;
+        if (batch) { for (int i = 0; i < batch->frames && ok; ++i) ok = near_enough(batch->cameras[i].origin); }
+        else ok = near_enough(ctx->camera.origin);
+        a.accel = ok ? 1 : 0;
+    }
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
@@ -746,6 +849,8 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         stats->node_slots = cnt[C_NODE_SLOTS]; stats->tri_slots = cnt[C_TRI_SLOTS]; stats->adv_slots = cnt[C_ADV_SLOTS]; stats->adv_active = cnt[C_ADV_ACTIVE];
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
         stats->wave_ticks = cnt[C_WAVE_TICKS];
+        stats->certificate_fallbacks = cnt[C_CERT_FALLBACKS];
+        stats->certified_tree_used = a.accel;
         {   // time marks relative to the first wave's start, in ms (0 when the mark was never passed)
             const double t0 = (double)~cnt[C_T_FIRST];
             stats->heavy_queue_empty_ms = cnt[C_T_HEAVY_EMPTY] ? (float)(((double)~cnt[C_T_HEAVY_EMPTY] - t0) * 1e-5) : 0.0f;

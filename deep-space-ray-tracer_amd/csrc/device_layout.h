@@ -72,7 +72,13 @@ struct DeviceScene {
     float root_lo[3];
     float root_hi[3];
     int   root_ref;            // kRefNone when there is no BVH
-    int   stack_need;          // deepest the traversal stack can get for this BVH
+    int   stack_need;          // deepest the traversal stack can get for this BVH (the deeper of the two trees when there are two)
+    // The certified second tree (device_api.hip: pack_scene; path_machine.h: the certificate).  Both trees live in the SAME arrays -- the second tree's node
+    // records, pair records and shading records first, the reference tree's behind them -- so a reference is a reference whichever tree a lane is on.
+    const float4* tri_cert;    // per slot OF THE SECOND TREE, 2 x float4: the box of the triangle's leaf ON THE REFERENCE TREE (lo.xyz, hi.x) (hi.yz, -, -); null = no second tree
+    int   accel_root_ref;      // the second tree's root (kRefNone: none)
+    float accel_root_lo[3];
+    float accel_root_hi[3];
 };
 
 constexpr int kCamOrigin = 0, kCamLlc = 3, kCamHorizontal = 6, kCamVertical = 9;     // offsets into FrameParams::cam / BatchFrame::cam
@@ -143,13 +149,14 @@ struct RenderArgs {
     int       steal;           // rng_mode 1: 1 = a lane that is out of work takes over half the remaining samples of a busy lane of its wave
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
     int       deal_leaves;     // 1: a parked leaf's second pair record is evaluated by a lane that is not at a leaf (render_kernel.hip, phase L)
+    int       accel;           // 1: rays start on the certified second tree and fall back to the reference tree when the certificate fails (path_machine.h)
 };
 
 // order matches the DsrtStats tail in include/dsrt.h
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
                C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
-               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_WAVE_TICKS,
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_CERT_FALLBACKS, C_WAVE_TICKS,
                C_T_FIRST, C_T_HEAVY_EMPTY, C_T_LIGHT_EMPTY, C_T_LAST,      // wall-clock marks (100 MHz ticks), kept as maxima: the first three of ~t
                kNumCounters };
 

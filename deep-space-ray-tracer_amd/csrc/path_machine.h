@@ -36,6 +36,11 @@ enum : int {
 //   pend strip while a ray is delegated: [0..2] the contribution, [3..5] shadow origin, [6..8] shadow direction,
 //              [12] the answer: 0 pending, 1 blocked, 2 clear;  row 13: the wave's request table (owner lane per request rank)
 constexpr uint32_t kAwait = 1u << 8;
+// The certified second tree (args.accel; device_api.hip: pack_scene).  A ray starts on the second tree with its distance culling relaxed by kCullRelax; when its walk
+// ends, the CERTIFICATE decides whether the answer is provably the reference walk's (advance_step), and if not the same ray walks the reference tree.
+//              bit 10 kOnRef: this ray is (re-)walking the reference tree: its answer is final;  bit 11 kTie: the last accept on the second tree was an equality accept
+constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11;
+constexpr float kCullRelax = 1.0f + 1.0f / 1024.0f;
 constexpr uint32_t kHot = 1u << 9;           // rng_mode 0: the pixel this lane is working on belongs to a heavy tile (its wave asks for issue priority)
 
 // Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
@@ -60,6 +65,8 @@ struct Lane {
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
     int cur = kRefNone, sp = 0, hit_slot = -1;
     float closest = kTMax, hit_u = 0.0f, hit_v = 0.0f;
+    float cull = kTMax;                          // what BOXES are culled against: `closest` itself on the reference tree, closest * kCullRelax on the second tree
+    float relax = 1.0f;                          // cull = closest * relax
     uint32_t steps = 0;
     // The continuation postponed while a shadow ray is in flight (sun term, next throughput, next ray, "path ends") is
     // 13 words that nothing touches during the walk: it lives in LDS, one column per lane, not in registers.
@@ -163,6 +170,38 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     if (state == ST_ENDING) end_sample();
 
     int launch = 0;         // set by a block that leaves a new ray in (ro, rd): 1 = closest-hit ray, 2 = shadow ray
+
+    // THE CERTIFICATE (include/dsrt.h, dsrt_ctx_set_certified_tree).  A walk of the second tree has ended with a triangle T: the accepted triangle of smallest t (closest-hit
+    // rays) or some accepted triangle (any-hit shadow rays).  The reference's walk of ITS tree returns the same T -- same t, u, v: Moller-Trumbore knows no tree -- if
+    //   (1) T can be reached there at all            -- triangles under a zero-thickness box were left out of the second tree;
+    //   (2) no other accepted triangle has EXACTLY T's t  (the reference keeps whichever it tests last, :353)                             -- kTie, kept by apply_pair;
+    //   (3) T's leaf box ON THE REFERENCE TREE, in the reference's own slab arithmetic, is passed with t_entry < t_T                       -- slab() on tri_cert, below:
+    //       every ancestor's box contains the leaf's and the slab arithmetic is monotone in the box bounds (float subtraction and multiplication by one fixed 1/d
+    //       round monotonically), so every ancestor is entered no later and left no earlier; `closest` never falls below t_T, the minimum; hence every box on the
+    //       root-to-leaf path passes whenever the reference tests it, T is tested against a closest >= t_T and accepted, and nothing accepted later has t <= t_T;
+    //   (4) no direction component is zero (0 * inf in the slab arithmetic is outside that argument).
+    // A shadow ray only asks whether ANY accepted triangle is reachable: (3) for the one found says so (either the reference reaches it, or it has already found another).
+    // A ray that found nothing found nothing: the second tree's walk is conservative (boxes widened at upload, distance culling relaxed by kCullRelax).
+    // A ray that fails any condition walks the reference tree -- the same ray, from the root, with the reference's own culling -- and that answer is final.
+    if (args.accel) {
+        if ((state == ST_SHADE || state == ST_SHADOW_DONE) && hit_slot >= 0 && !(ln.aux & kOnRef)) {
+            const float4* cb = S.tri_cert + (size_t)hit_slot * 2;
+            const float4 c0 = cb[0], c1 = cb[1];
+            float t_entry;
+            const bool certified = slab(mk(c0.x, c0.y, c0.z), mk(c0.w, c1.x, c1.y), ro, rinv, closest, t_entry) && !(ln.aux & kTie) &&
+                                   rd.x != 0.0f && rd.y != 0.0f && rd.z != 0.0f;
+            if (!certified) {
+                if (COUNT) c[C_CERT_FALLBACKS]++;
+                ln.aux = (ln.aux | kOnRef) & ~kTie;
+                closest = kTMax; ln.cull = kTMax; ln.relax = 1.0f;
+                hit_slot = -1;
+                sp = 0;
+                steps = 0;
+                // the head of bvh_hit_closest :394-410 on the reference tree; a miss of its root box leaves the ray in ST_SHADE / ST_SHADOW_DONE without a hit
+                if (S.root_ref != kRefNone && slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state += ST_TRAV_CLOSEST - ST_SHADE; }
+            }
+        }
+    }
 
     if (state == ST_SHADOW_DONE) {
         // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
@@ -609,10 +648,16 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         sp = 0;
         steps = 0;
         state = ST_SHADE - 1 + launch;                 // ST_SHADE for a closest-hit ray, ST_SHADOW_DONE for a shadow ray
-        if (S.root_ref != kRefNone) {
+        // which tree the ray starts on: the certified second tree when the launch uses it (wave-uniform), the reference tree otherwise
+        const bool second = args.accel != 0;
+        ln.cull = kTMax;
+        ln.relax = second ? kCullRelax : 1.0f;
+        ln.aux &= ~(kOnRef | kTie);
+        const int root_ref = second ? S.accel_root_ref : S.root_ref;
+        if (root_ref != kRefNone) {
             if (COUNT) c[C_BOX_FETCHES]++;
             float t_entry;
-            if (slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state = ST_TRAV_CLOSEST - 1 + launch; }
+            if (slab(ld3(second ? S.accel_root_lo : S.root_lo), ld3(second ? S.accel_root_hi : S.root_hi), ro, rinv, closest, t_entry)) { cur = root_ref; state = ST_TRAV_CLOSEST - 1 + launch; }
         }
         // nothing to walk and no spheres to test: a closest-hit ray has missed the scene (:744-747)
         if (state == ST_SHADE && num_spheres == 0) end_sample();

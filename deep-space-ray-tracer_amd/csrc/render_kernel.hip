@@ -73,13 +73,16 @@ __device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2
     bool stop = false;
     if (COUNT) c[C_TRI_TESTS]++;
     if (ok_a && !(t.x > ln.closest)) {
-        ln.closest = t.x; ln.hit_slot = slot_a; ln.hit_u = u.x; ln.hit_v = v.x;
+        // (certified second tree, path_machine.h) an equality accept over an earlier hit is a TIE: the reference's answer would depend on its own order
+        ln.aux = (t.x == ln.closest && ln.hit_slot >= 0) ? (ln.aux | kTie) : (ln.aux & ~kTie);
+        ln.closest = t.x; ln.cull = t.x * ln.relax; ln.hit_slot = slot_a; ln.hit_u = u.x; ln.hit_v = v.x;
         if (COUNT) c[C_HIT_UPDATES]++;
         stop = ANYHIT && ln.state == ST_TRAV_SHADOW;
     }
     if (COUNT && has_b && !stop) c[C_TRI_TESTS]++;
     if (!stop && ok_b && !(t.y > ln.closest)) {          // an absent B is all zeros: det == 0, never ok
-        ln.closest = t.y; ln.hit_slot = slot_a + 1; ln.hit_u = u.y; ln.hit_v = v.y;
+        ln.aux = (t.y == ln.closest && ln.hit_slot >= 0) ? (ln.aux | kTie) : (ln.aux & ~kTie);
+        ln.closest = t.y; ln.cull = t.y * ln.relax; ln.hit_slot = slot_a + 1; ln.hit_u = u.y; ln.hit_v = v.y;
         if (COUNT) c[C_HIT_UPDATES]++;
         stop = ANYHIT && ln.state == ST_TRAV_SHADOW;
     }
@@ -103,7 +106,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
     ln.pend = &lds_pend[0][threadIdx.x];
     ln.aux = (uint32_t)lane;
     int& state = ln.state; int& cur = ln.cur; int& sp = ln.sp;
-    float& closest = ln.closest; uint32_t& steps = ln.steps;
+    uint32_t& steps = ln.steps;
     F3& ro = ln.ro; F3& rd = ln.rd; F3& rinv = ln.rinv;
     uint32_t c[kNumCounters];
 #pragma unroll
@@ -202,7 +205,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         if (wave_any(sp >= K)) {               // wave-uniform guard: keeps the common path a plain ds_read_b64 (without it: +3 %)
                             if (sp >= K) e = args.spill[(size_t)(sp - K) * args.spill_stride + glane];
                         }
-                        if (closest > __uint_as_float(e.y)) cur = (int)e.x;
+                        if (ln.cull > __uint_as_float(e.y)) cur = (int)e.x;                // (cull == closest on the reference tree: the reference's own test)
                     }
                 }
 
@@ -230,8 +233,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
                         const float t0yl = ny ? by.x : ay.x, t1yl = ny ? ay.x : by.x, t0yr = ny ? by.y : ay.y, t1yr = ny ? ay.y : by.y;
                         const float t0zl = nz ? bz.x : az.x, t1zl = nz ? az.x : bz.x, t0zr = nz ? bz.y : az.y, t1zr = nz ? az.y : bz.y;
                         const float tl = fmaxf(fmaxf(kTMin, t0xl), fmaxf(t0yl, t0zl)), tr = fmaxf(fmaxf(kTMin, t0xr), fmaxf(t0yr, t0zr));
-                        const bool hl = !(fminf(fminf(closest, t1xl), fminf(t1yl, t1zl)) <= tl);
-                        const bool hr = !(fminf(fminf(closest, t1xr), fminf(t1yr, t1zr)) <= tr);
+                        const bool hl = !(fminf(fminf(ln.cull, t1xl), fminf(t1yl, t1zl)) <= tl);
+                        const bool hr = !(fminf(fminf(ln.cull, t1xr), fminf(t1yr, t1zr)) <= tr);
                         // nearer child by box centre along the ray :433-453 (only matters when both are hit).  The reference compares
                         //   d = ((c.x - o.x) * dir.x + (c.y - o.y) * dir.y) + (c.z - o.z) * dir.z,   c = 0.5f * (lo + hi)
                         // of the two children.  Computed here is 2 d, with the reference's roundings: s = lo + hi is the reference's sum (the x sums come with the record); the product

@@ -143,19 +143,20 @@ struct SahBuilder {
 
 }  // namespace
 
-extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
-    return dsrt::guarded("dsrt_host_scene_build_bvh_sah", [&]() -> int {
-    if (!hs) { dsrt::set_error("dsrt_host_scene_build_bvh_sah: null scene"); return DSRT_ERR_INVALID; }
-    hs->tri_indices.clear();
-    hs->nodes.clear();
-    hs->bvh_height = 0;
-    const size_t n = hs->tris.size();
-    if (n == 0) { hs->bvh_valid = true; return DSRT_OK; }
+namespace dsrt {
+
+// The builder on plain arrays (host_internal.hpp).  `pad_all` > 0 widens EVERY triangle box by that much on every side (the certified second tree of
+// device_api.hip needs boxes that no rounding of the slab arithmetic can make a hit triangle miss); `skip` (may be null) marks triangles to leave out.
+int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out) {
+    nodes.clear();
+    order.clear();
+    height_out = 0;
+    if (n == 0) return DSRT_OK;
     if (n > (size_t)1 << 28) { dsrt::set_error("more than 2^28 triangles"); return DSRT_ERR_INVALID; }
     std::vector<Box> tri_box(n);
     std::vector<float> centroid(3 * n);
     for (size_t i = 0; i < n; ++i) {
-        const GPUTriangle& t = hs->tris[i];
+        const GPUTriangle& t = tris[i];
         const float v[3][3] = {{t.v0.x, t.v1.x, t.v2.x}, {t.v0.y, t.v1.y, t.v2.y}, {t.v0.z, t.v1.z, t.v2.z}};
         for (int a = 0; a < 3; ++a) {
             tri_box[i].lo[a] = fminf(fminf(v[a][0], v[a][1]), v[a][2]);
@@ -174,22 +175,38 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], tri_box[i].lo[a]); hi[a] = fmaxf(hi[a], tri_box[i].hi[a]); }
         const float pad = dsrt::flat_box_pad(fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]));
         for (size_t i = 0; i < n; ++i)
-            for (int a = 0; a < 3; ++a)
-                if (tri_box[i].lo[a] == tri_box[i].hi[a]) { tri_box[i].lo[a] -= pad; tri_box[i].hi[a] += pad; }
+            for (int a = 0; a < 3; ++a) {
+                if (pad_all > 0.0f) { tri_box[i].lo[a] -= pad_all; tri_box[i].hi[a] += pad_all; }
+                else if (tri_box[i].lo[a] == tri_box[i].hi[a]) { tri_box[i].lo[a] -= pad; tri_box[i].hi[a] += pad; }
+            }
     }
-    hs->tri_indices.resize(n);
-    for (size_t i = 0; i < n; ++i) hs->tri_indices[i] = (int)i;
-    hs->nodes.reserve(n);
-    SahBuilder b{tri_box, centroid, hs->tri_indices};
+    order.reserve(n);
+    for (size_t i = 0; i < n; ++i) if (!skip || !skip[i]) order.push_back((int)i);
+    if (order.empty()) return DSRT_OK;
+    nodes.reserve(order.size());
+    SahBuilder b{tri_box, centroid, order};
     int height = 0, fork = 0;
     for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 4; t >>= 1) ++fork;
-    b.build(0, (int)n, 1, hs->nodes, height, fork);
-    hs->bvh_height = height;
-    hs->bvh_valid = true;
-    if (hs->bvh_height - 1 > 64) {
+    b.build(0, (int)order.size(), 1, nodes, height, fork);
+    height_out = height;
+    if (height - 1 > 64) {
         dsrt::set_error("SAH BVH needs a traversal stack deeper than 64 entries");
         return DSRT_ERR_BVH_DEPTH;
     }
+    return DSRT_OK;
+}
+
+}  // namespace dsrt
+
+extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
+    return dsrt::guarded("dsrt_host_scene_build_bvh_sah", [&]() -> int {
+    if (!hs) { dsrt::set_error("dsrt_host_scene_build_bvh_sah: null scene"); return DSRT_ERR_INVALID; }
+    hs->tri_indices.clear();
+    hs->nodes.clear();
+    hs->bvh_height = 0;
+    const int rc = dsrt::build_sah_tree(hs->tris.data(), hs->tris.size(), 0.0f, nullptr, hs->nodes, hs->tri_indices, hs->bvh_height);
+    if (rc != DSRT_OK) return rc;
+    hs->bvh_valid = true;
     return DSRT_OK;
     });
 }

@@ -35,7 +35,7 @@ const char* dsrt_last_error(void);
 /* ABI version: THE one place it is written.  Bumped on any signature, struct or flag change (3 = round 2: DsrtStats grew,
  * dsrt_render_batch, dsrt_multi_*; 4 = round 3: DsrtRenderDesc.tune[3] pruned to the switches a host may need, reserved bits
  * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended;
- * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof, dsrt_dev_set_experiment, dsrt_selftest_poke_node_word).  dsrt_abi_version() returns the value the library was compiled with;
+ * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof, dsrt_dev_set_experiment, dsrt_selftest_poke_node_word, dsrt_ctx_set_certified_tree, DsrtStats grew).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
 #define DSRT_ABI_VERSION 7
 int dsrt_abi_version(void);
@@ -172,6 +172,20 @@ void dsrt_ctx_destroy(DsrtContext* ctx);
 int  dsrt_ctx_clone(const DsrtContext* src, DsrtContext** out);
 int  dsrt_ctx_device(const DsrtContext* ctx);
 
+/* THE CERTIFIED SECOND TREE (round 4).  The reference's answer to a BVH query depends on its own median-split tree only in three narrow ways: triangles under
+ * a zero-thickness box are never reached (src/gpu_render.cu:312), of two accepted triangles at exactly the same t the one tested later wins (:353), and a hit
+ * computed in front of its own leaf box's entry distance is found or not depending on what was found before.  Everywhere else the answer is simply the accepted
+ * triangle of smallest t -- whatever tree found it.  With this option the next dsrt_scene_upload also builds a binned-SAH tree over the reachable triangles
+ * (boxes widened by 2^-16 of the scene's extent); a ray walks THAT tree (a third fewer node visits on a mesh of long thin members), the kernel then checks the
+ * three conditions exactly -- no tie, the hit inside its REFERENCE-leaf box's slab interval as the reference's own arithmetic computes it, no zero direction
+ * component -- and any ray that fails one is walked again on the reference tree (a handful per million).  The image is the reference's, byte for byte, provided
+ * Moller-Trumbore's computed t of every accepted triangle is accurate to 2^-10 relative (the margin by which the second tree's distance culling is relaxed):
+ * tests/test_gpu_certified_tree.py compares whole frames, the headline frame included, with the reference kernel's own images.  Off by default; the
+ * environment variable DSRT_CERTIFIED_TREE=1 switches it on for contexts created afterwards (the drop-in gpu_render_scene included).  Costs one more tree in HBM
+ * (about as much again as the scene) and the SAH build at upload (0.2 s per million triangles).  DSRT_TUNE_REFERENCE_WALK renders without it. */
+int  dsrt_ctx_set_certified_tree(DsrtContext* ctx, int on);
+int  dsrt_ctx_has_certified_tree(const DsrtContext* ctx);
+
 /* Upload + re-layout for the GPU (once per scene, not per frame).  `scene` holds HOST pointers in the
  * reference layouts (as from dsrt_host_scene_view); its camera/params/sun are recorded as the current frame.
  * Replaces the upload half of build_gpu_scene (src/gpu_scene_builder.cpp:322-331, 475-546). */
@@ -231,7 +245,8 @@ typedef struct DsrtRenderDesc {
 #define DSRT_TUNE_NO_PROBE        8    /* no probe launch to refine the tile order (rng_mode 0)                               */
 #define DSRT_TUNE_NO_STEALING    16    /* rng_mode 1: idle lanes do not take over samples of busy lanes                       */
 #define DSRT_TUNE_NO_PRIORITY    32    /* rng_mode 0: waves holding a heavy tile's pixel do not raise their issue priority    */
-#define DSRT_TUNE_FLAG_MASK      63
+#define DSRT_TUNE_REFERENCE_WALK 64    /* every ray walks the reference tree even when the certified second tree is resident   */
+#define DSRT_TUNE_FLAG_MASK      127
 
 typedef struct DsrtStats {
     float    kernel_ms;             /* HIP events around the render kernel on the given stream (0 if timing off) */
@@ -252,8 +267,11 @@ typedef struct DsrtStats {
     /* counting build: sum over the waves of the time each spent in the kernel, in ticks of the 100 MHz wall clock; divided by
      * (waves_launched x kernel time) it is the fraction of the launch the average wave was resident */
     uint64_t wave_ticks;
+    /* counting build, certified second tree in use: BVH queries whose certificate failed and which were walked again on the reference tree */
+    uint64_t certificate_fallbacks;
     /* counting build, ms after the first wave started: the heavy / the light work queue handed out its last item, the last wave left */
     float    heavy_queue_empty_ms, light_queue_empty_ms, last_wave_exit_ms;
+    int      certified_tree_used;   /* 1: the rays of this launch started on the certified second tree (dsrt_ctx_set_certified_tree) */
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of

@@ -369,11 +369,11 @@ def test_scheduling_switches_never_change_a_pixel(dsrt, gpu_ctx, oracle):
     scene = hs.view(cam, SUN)
     want_rgb, want_f32, _ = oracle.render(scene, W, H)
     gpu_ctx.upload(scene)
-    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 36, 63 - 1):        # include/dsrt.h, DSRT_TUNE_*
+    for flags in (0, 1, 2, 4, 8, 12, 5, 14, 32, 36, 63 - 1, 64):        # include/dsrt.h, DSRT_TUNE_*
         rgb, f32, _ = gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)), want_f32=True)
         assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32)), flags
     # bits the ABI does not define are refused, not ignored
-    for flags in (64, 1 << 23, -(1 << 31)):
+    for flags in (128, 1 << 23, -(1 << 31)):
         with pytest.raises(dsrt.DsrtError):
             gpu_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, tune=(0, 0, 0, flags)))
     # the development switches (dsrt_dev_set_experiment) are scheduling only as well; undefined bits are refused

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shards", type=int, default=1)
     ap.add_argument("--bvh", type=str, default="median")
+    ap.add_argument("--certified", action="store_true", help="upload with the certified second tree (dsrt_ctx_set_certified_tree); a sixth config field of 1 then renders on the "
+                                                              "plain reference walk (DSRT_TUNE_REFERENCE_WALK), e.g. 0:0 0:0:0:0:0:1")
     a = ap.parse_args()
     import torch
     import dsrt_amd as d
@@ -39,6 +41,8 @@ def main():
     W, H, spp = a.width, a.height, a.spp
     cam = d.frame_camera(fr, 40.0, W, H, spp, 50)
     ctx = d.Context(0)
+    if a.certified:
+        ctx.set_certified_tree(True)
     ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
     stream = torch.cuda.current_stream().cuda_stream
     n = a.shards
@@ -47,7 +51,8 @@ def main():
         parts = [int(x) for x in c.split(":")]
         rng, t3 = parts[0], parts[1]
         t0, t1, t2 = (parts[2:5] + [0, 0, 0])[:3]                     # optional: min_walk_iters : advance_budget : leaf_ratio4
-        descs.append((d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, t3 & 63)), (t3 & 0xFFFFFFFF) & ~63))
+        walk = 64 if len(parts) > 5 and parts[5] else 0               # DSRT_TUNE_REFERENCE_WALK
+        descs.append((d.make_desc(W, H, spp, 50, shard_rank=0, shard_count=n if n > 1 else 0, rng_mode=rng, tune=(t0, t1, t2, (t3 & 63) | walk)), (t3 & 0xFFFFFFFF) & ~63))
     lay = d.shard_layout(descs[0][0])
     buf = torch.zeros(lay["rgb8_bytes_padded"] if n > 1 else W * H * 3, dtype=torch.uint8, device="cuda")
     import time
