@@ -14,6 +14,11 @@ deep-space-ray-tracer_amd/meshgen.py is generated (--tris, default 1,000,000 tri
 rendezvous_1s_dt0_01s.txt (tests/golden/ copy).  The default frame is 98 (camera 35.7 m from the station, which fills the view);
 frame 0 (1787 m, 99.9 % of the tiles provably empty and culled) is reported in `extras` as what it is: a culling rate.
 
+Tree: by default rays walk the CERTIFIED SECOND TREE (include/dsrt.h, dsrt_ctx_set_certified_tree): a SAH tree whose every answer the kernel certifies against the
+reference's own median-split tree, re-walking that tree when it cannot -- the reference's bytes with a third fewer node visits.  The line proves it on the run itself:
+`reference_kernel_fixture` compares the image of the last timed step with the image the reference's own kernel rendered of this frame (tests/golden/), `parity_rows`
+with the CPU oracle's rows; `extras.reference_walk_only` times the same frame with every ray on the reference tree (`--tree reference` makes that the headline).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and, at N = 1, `cpu_baseline`.
 
 roofline.  The path is branchy fp32 vector arithmetic over a scene that lives in L2 / Infinity Cache; the counters say it is bound
@@ -45,6 +50,8 @@ import sys
 import tempfile
 import threading
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -464,9 +471,15 @@ def main():
     ap.add_argument("--batch", type=int, default=99, help="--sequence: render the poses through dsrt_render_batch, this many frames per launch (0 = one launch per frame, --inflight of them overlapping)")
     ap.add_argument("--tune012", type=str, default="0:0:0", help="--sequence: DsrtRenderDesc.tune[0..2] = min_walk_iters:advance_budget:leaf_ratio4 (development aid)")
     ap.add_argument("--tune3", type=int, default=0, help="--sequence: DsrtRenderDesc.tune[3], the DSRT_TUNE_* switches of include/dsrt.h (development switches: env DSRT_EXPERIMENT)")
+    ap.add_argument("--tree", choices=["certified", "reference"], default="certified",
+                    help="certified (default): rays walk the certified second tree (dsrt_ctx_set_certified_tree: a SAH tree whose every answer the kernel certifies against the "
+                         "reference's median-split tree, re-walking that tree when it cannot) -- the reference's bytes, checked against the reference kernel's own image in this "
+                         "line; reference: every ray walks the reference tree (the plain walk; also timed as extras.reference_walk_only)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.tree == "certified" and args.bvh == "median":
+        os.environ.setdefault("DSRT_CERTIFIED_TREE", "1")          # contexts the library creates itself (dsrt_multi_*, the drop-in gpu_render_scene) follow the same choice
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1 and not args.single_process and not args.pmc_child:
         spawn_distributed(args.gpus)                                   # never returns
@@ -582,10 +595,15 @@ def main():
         return
 
     ctx = d.Context(local_rank)
+    certified = args.tree == "certified" and args.bvh == "median"
+    if certified:
+        ctx.set_certified_tree(True)
     t0 = time.perf_counter()
     ctx.upload(scene)
     torch.cuda.synchronize()
     setup["pack_and_upload_s"] = time.perf_counter() - t0
+    if certified:
+        setup["pack_and_upload_includes"] = "the SAH build of the certified second tree and both trees' re-layout"
 
     if args.pmc_child:                               # the run rocprofv3 watches: this workload's kernel, twice, nothing else
         part = torch.zeros(W * H * 3, dtype=torch.uint8, device=dev)
@@ -805,6 +823,7 @@ def main():
                           "instead of the reference's median split (non-parity fast mode, SURVEY.md 8(f) n4)",
                   "runs": [dict(measure(0, 0), bvh=args.bvh), dict(measure(args.frame, 1), bvh=args.bvh), dict(measure(0, 1), bvh=args.bvh)]}
         if args.bvh == "median":
+            ctx.set_certified_tree(False)                            # the other trees are timed as what they are: plain walks
             hs_sah = d.HostScene().add_obj(obj)
             t0 = time.perf_counter()
             hs_sah.build_bvh("sah")
@@ -825,7 +844,8 @@ def main():
             except d.DsrtError as e:
                 extras["lbvh_error"] = str(e)[:200]
             del hs_l
-            ctx.upload(scene)                                       # back to the reference tree
+            ctx.set_certified_tree(certified)
+            ctx.upload(scene)                                       # back to the reference tree (and its certified second tree)
         ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
         # the reference's own three calls, end to end (src/main.cpp:405-428): build_gpu_scene (upload in the reference layouts) ->
         # gpu_render_scene (scene fetched back, re-laid-out, uploaded, rendered, PPM written) -> free_gpu_scene; once cold, once warm
@@ -855,10 +875,14 @@ def main():
         # two reference points for reading the numbers above: what this board's HBM does on a plain
         # device-to-device copy, and the headline frame end to end into pinned host memory (render + 6 MB copy)
         try:
-            cp = d.microbench_copy(2 << 30, 8, 8, device=local_rank)              # float4 grid-stride copy, 2 GiB per buffer (8x the Infinity Cache), read + write counted
-            extras["hbm_copy_GBps_measured"] = cp["GBps"]
-            extras["hbm_copy_how"] = ("dsrt_microbench_copy: float4 grid-stride kernel, 8 workgroups of 256 per CU, 2 GiB src + 2 GiB dst, 8 launches, bytes read + written / HIP-event "
-                                      "time (the guide's figure for this pattern: 6.29 TB/s = 79 % of the 8 TB/s specification)")
+            # float4 grid-stride copy, 2 GiB per buffer (8x the Infinity Cache), read + write counted; the best of four grid sizes
+            sweep = {bpc: d.microbench_copy(2 << 30, bpc, 6, device=local_rank)["GBps"] for bpc in (4, 8, 16, 32)}
+            extras["hbm_copy_GBps_measured"] = max(sweep.values())
+            extras["hbm_copy_GBps_by_workgroups_per_cu"] = sweep
+            extras["hbm_copy_how"] = ("dsrt_microbench_copy: float4 grid-stride kernel (4 independent 16-byte loads in flight per lane), 256-thread workgroups, 2 GiB src + 2 GiB dst, "
+                                      "6 launches, bytes read + written / HIP-event time, best of 4 / 8 / 16 / 32 workgroups per CU.  The guide quotes 6.29 TB/s for a float4 copy; the "
+                                      "boxes of this pool gave 4.4-4.8 TB/s to this kernel in every grid shape, and 4.8 TB/s to hipMemcpy device-to-device (round 3): the figure is "
+                                      "this board's, not the kernel's")
         except d.DsrtError as e:
             extras["hbm_copy_GBps_measured"] = None
             extras["hbm_copy_how"] = str(e)[:160]
@@ -869,24 +893,20 @@ def main():
         pinned.copy_(part[:W * H * 3], non_blocking=True)
         torch.cuda.synchronize()
         extras["frame_to_pinned_host_ms"] = (time.perf_counter() - t0) * 1e3
-        # The reference-identical mode at the headline size.  math_mode 1 = the same kernels compiled with cosf / sinf / powf from the device math library: the bytes of
-        # the reference's own kernel as built for this GPU (oracle/_ref/ref_gpu; tests/golden/ref_gpu_images.json holds its image of exactly this frame).
-        try:
-            d1 = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, math_mode=1)
-            ctx.render(d1, part.data_ptr(), stream=stream, want_stats=True)       # warm-up
-            torch.cuda.synchronize()
-            k1 = []
-            t0 = time.perf_counter()
-            for _ in range(max(2, args.steps)):
-                k1.append(ctx.render(d1, part.data_ptr(), stream=stream, want_stats=True).kernel_ms)
-            torch.cuda.synchronize()
-            per = (time.perf_counter() - t0) / len(k1)
-            extras["math_mode_1"] = {"ms_per_step": per * 1e3, "Msamples/s": W * H * spp / per / 1e6, "kernel_ms": sum(k1) / len(k1), "steps": len(k1),
-                                     "what": "same frame, same launch path, the kernels compiled against the device math library: byte-identical to the reference's kernel as built "
-                                             "for this GPU with contraction off (hipify-perl + hipcc; nvcc's default contraction and libdevice are not reproducible here)",
-                                     "reference_kernel_fixture": fixture_check(part[:W * H * 3].cpu().numpy().reshape(H, W, 3), "ref_gpu_images.json", args, obj, W, H, spp, depth)}
-        except Exception as e:  # noqa: BLE001 -- an extra never stops the bench
-            extras["math_mode_1"] = {"error": str(e)[:200]}
+        # The same frame with every ray on the reference tree (DSRT_TUNE_REFERENCE_WALK): what the certified second tree buys, and the plain walk's own speed.
+        if certified:
+            try:
+                dr = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, tune=(0, 0, 0, 64))
+                ctx.render(dr, part.data_ptr(), stream=stream, want_stats=True)
+                kr = [ctx.render(dr, part.data_ptr(), stream=stream, want_stats=True).kernel_ms for _ in range(2)]
+                same = bool(headline_image is not None and np.array_equal(part[:W * H * 3].cpu().numpy().reshape(H, W, 3), headline_image))
+                cr = ctx.render(d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, tune=(0, 0, 0, 64), collect_counters=1), part.data_ptr(), stream=stream, want_stats=True)
+                extras["reference_walk_only"] = {"kernel_ms": min(kr), "Msamples/s": W * H * spp / min(kr) / 1e3, "image_equals_the_headline_image": same if headline_image is not None else None,
+                                                 "nodes_entered_per_ray": cr.nodes_entered / max(1, cr.rays), "tri_tests_per_ray": cr.tri_tests / max(1, cr.rays),
+                                                 "algorithmic_bytes_per_launch": algorithmic_bytes(cr, W * H),
+                                                 "what": "DSRT_TUNE_REFERENCE_WALK: every ray walks the reference's median-split tree, nothing else changed"}
+            except Exception as e:  # noqa: BLE001
+                extras["reference_walk_only"] = {"error": str(e)[:200]}
         # the headline frame four times over as ONE batch launch (dsrt_render_batch): what is left of the step when a frame's last chains run
         # under the next frame's bulk.  The headline itself stays one launch per step, each waited for.
         try:
@@ -906,6 +926,24 @@ def main():
             del batch_img
         except Exception as e:  # noqa: BLE001 -- an extra never stops the bench
             extras["headline_frame_x4_as_one_batch_launch"] = {"error": str(e)[:200]}
+        # The reference-identical mode at the headline size.  math_mode 1 = the same kernels compiled with cosf / sinf / powf from the device math library: the bytes of
+        # the reference's own kernel as built for this GPU (oracle/_ref/ref_gpu; tests/golden/ref_gpu_images.json holds its image of exactly this frame).
+        try:
+            d1 = d.make_desc(W, H, spp, depth, stack_entries=args.stack_entries, math_mode=1)
+            ctx.render(d1, part.data_ptr(), stream=stream, want_stats=True)       # warm-up
+            torch.cuda.synchronize()
+            k1 = []
+            t0 = time.perf_counter()
+            for _ in range(max(2, args.steps)):
+                k1.append(ctx.render(d1, part.data_ptr(), stream=stream, want_stats=True).kernel_ms)
+            torch.cuda.synchronize()
+            per = (time.perf_counter() - t0) / len(k1)
+            extras["math_mode_1"] = {"ms_per_step": per * 1e3, "Msamples/s": W * H * spp / per / 1e6, "kernel_ms": sum(k1) / len(k1), "steps": len(k1),
+                                     "what": "same frame, same launch path, the kernels compiled against the device math library: byte-identical to the reference's kernel as built "
+                                             "for this GPU with contraction off (hipify-perl + hipcc; nvcc's default contraction and libdevice are not reproducible here)",
+                                     "reference_kernel_fixture": fixture_check(part[:W * H * 3].cpu().numpy().reshape(H, W, 3), "ref_gpu_images.json", args, obj, W, H, spp, depth)}
+        except Exception as e:  # noqa: BLE001 -- an extra never stops the bench
+            extras["math_mode_1"] = {"error": str(e)[:200]}
 
     # ---- roofline: calibration kernels live, PMC counters of this workload from child passes ----
     roof = None
@@ -936,7 +974,7 @@ def main():
             pmc = None
             if not args.no_pmc:
                 wl = ["--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", str(depth), "--frame", str(args.frame), "--tris", str(args.tris),
-                      "--bvh", args.bvh, "--stack-entries", str(args.stack_entries)] + (["--obj", args.obj] if args.obj else [])
+                      "--bvh", args.bvh, "--tree", args.tree, "--stack-entries", str(args.stack_entries)] + (["--obj", args.obj] if args.obj else [])
                 pmc = pmc_counters(wl)
             if pmc:
                 clk = pmc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / secs if secs > 0 else 0.0          # Hz (sum over the 8 XCDs)
@@ -1000,6 +1038,13 @@ def main():
                 "tiles_total_rank0": int(tiles_total), "tiles_culled_rank0": int(tiles_culled),
                 "parallelism": f"screen tiles 8x8 interleaved over {n_gpus} GPU(s)" + (", one RCCL gather + de-interleave per step" if shard else ""),
                 "bvh": args.bvh, "bvh_stack_need": hs.stack_need, "lds_stack_entries": st.lds_stack_entries,
+                "tree": ("certified second tree: rays walk a binned-SAH tree over the reachable triangles; the kernel certifies every answer against the reference's median-split tree "
+                         "(no exact tie, inside the reference-leaf box's slab interval, no zero direction component) and re-walks the reference tree otherwise. The image is the "
+                         "reference's, byte for byte: reference_kernel_fixture below compares THIS run's image with the reference kernel's own") if certified else
+                        "reference tree only (every ray walks the reference's median-split tree)",
+                "certified_tree_used_rank0": int(last_stats[0].certified_tree_used) if last_stats else None,
+                "certificate_fallbacks_in_the_counting_launch": int(st.certificate_fallbacks), "nodes_entered_per_ray": st.nodes_entered / max(1, st.rays),
+                "tri_tests_per_ray": st.tri_tests / max(1, st.rays),
                 "math_mode": 0,
                 "math_mode_note": "the headline runs in math_mode 0: cosf / sinf / powf from include/dsrt_detmath.h, the one image every machine (the CPU oracle included) reproduces; it "
                                   "equals the reference's kernel built with those three functions (reference_kernel_fixture below). The mode that equals the reference's kernel built "

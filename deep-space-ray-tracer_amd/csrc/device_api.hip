@@ -114,6 +114,12 @@ struct PackedScene {
 float4 as_f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 float bits(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 
+// Leaf size of the certified second tree (its structure is free: any tree over the reachable triangles will do).  Development override: DSRT_SECOND_TREE_LEAF=1..7.
+int second_tree_leaf_max() {
+    if (const char* e = std::getenv("DSRT_SECOND_TREE_LEAF")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 7) return (int)v; }
+    return 4;
+}
+
 // What packing one tree into the shared arrays yields.
 struct PackedTree { int root_ref = kRefNone; int stack_need = 0; float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
 
@@ -279,7 +285,7 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
             std::vector<GPUBVHNode> nodes2;
             std::vector<int> order2;
             int height2 = 0;
-            int rc = build_sah_tree(h.triangles, (size_t)N, extent > 0.0f ? extent * (1.0f / 65536.0f) : 1.0e-6f, unreachable.data(), nodes2, order2, height2);
+            int rc = build_sah_tree(h.triangles, (size_t)N, extent > 0.0f ? extent * (1.0f / 65536.0f) : 1.0e-6f, unreachable.data(), nodes2, order2, height2, second_tree_leaf_max());
             if (rc != DSRT_OK) return rc;
             if (!nodes2.empty()) {
                 if ((rc = pack_tree(h, nodes2.data(), (int)nodes2.size(), order2.data(), (int)order2.size(), textured, leaf_box.data(), arr, acc_tree))) return rc;

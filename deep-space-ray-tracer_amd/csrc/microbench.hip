@@ -446,7 +446,12 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
 // denominator next to the spec's 8 TB/s.  Buffers far beyond the 256 MB Infinity Cache, so that neither side is served on the die.
 __global__ void __launch_bounds__(256) dsrt_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {               // four independent 16-byte loads in flight per lane, then the four stores
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 extern "C" int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved) {

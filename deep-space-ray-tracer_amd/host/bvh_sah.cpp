@@ -31,7 +31,6 @@ struct Box {
 };
 
 constexpr int kBins = 32;
-constexpr int kLeafMax = 4;
 
 constexpr int kParallelMin = 1 << 15;       // ranges smaller than this are not worth a thread
 
@@ -39,6 +38,7 @@ struct SahBuilder {
     const std::vector<Box>& tri_box;
     const std::vector<float>& centroid;
     std::vector<int>& order;
+    int kLeafMax = 4;                       // the reference's leaf size
 
     // as in bvh_median.cpp: the two halves of a large range are built on two threads into node vectors of their own and spliced in pre-order
     int build(int start, int end, int level, std::vector<GPUBVHNode>& nodes, int& height, int fork) {
@@ -147,7 +147,7 @@ namespace dsrt {
 
 // The builder on plain arrays (host_internal.hpp).  `pad_all` > 0 widens EVERY triangle box by that much on every side (the certified second tree of
 // device_api.hip needs boxes that no rounding of the slab arithmetic can make a hit triangle miss); `skip` (may be null) marks triangles to leave out.
-int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out) {
+int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out, int leaf_max) {
     nodes.clear();
     order.clear();
     height_out = 0;
@@ -184,7 +184,7 @@ int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8
     for (size_t i = 0; i < n; ++i) if (!skip || !skip[i]) order.push_back((int)i);
     if (order.empty()) return DSRT_OK;
     nodes.reserve(order.size());
-    SahBuilder b{tri_box, centroid, order};
+    SahBuilder b{tri_box, centroid, order, leaf_max >= 1 && leaf_max <= 7 ? leaf_max : 4};
     int height = 0, fork = 0;
     for (unsigned t = dsrt::builder_threads(); t > 1 && fork < 4; t >>= 1) ++fork;
     b.build(0, (int)order.size(), 1, nodes, height, fork);
@@ -204,7 +204,7 @@ extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
     hs->tri_indices.clear();
     hs->nodes.clear();
     hs->bvh_height = 0;
-    const int rc = dsrt::build_sah_tree(hs->tris.data(), hs->tris.size(), 0.0f, nullptr, hs->nodes, hs->tri_indices, hs->bvh_height);
+    const int rc = dsrt::build_sah_tree(hs->tris.data(), hs->tris.size(), 0.0f, nullptr, hs->nodes, hs->tri_indices, hs->bvh_height, 4);
     if (rc != DSRT_OK) return rc;
     hs->bvh_valid = true;
     return DSRT_OK;

@@ -46,7 +46,7 @@ inline unsigned builder_threads() {
 }
 
 // bvh_sah.cpp: the binned-SAH builder on plain arrays (every triangle box widened by pad_all if > 0; triangles marked in `skip` left out)
-int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out);
+int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out, int leaf_max);
 
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);
