@@ -893,6 +893,20 @@ def main():
         pinned.copy_(part[:W * H * 3], non_blocking=True)
         torch.cuda.synchronize()
         extras["frame_to_pinned_host_ms"] = (time.perf_counter() - t0) * 1e3
+        # The certificate, audited ray by ray (collect_counters = 3): at 32 samples per pixel every answer of the second tree is also walked on the reference tree and compared.
+        if certified:
+            try:
+                aspp = min(spp, 32)
+                frx, camx, _ = frame_scene(args.frame)
+                ctx.set_camera_sun(d.frame_camera(frx, 40.0, W, H, aspp, depth), tuple(frx.sun_dir_model))
+                sa = ctx.render(d.make_desc(W, H, aspp, depth, stack_entries=args.stack_entries, collect_counters=3), part.data_ptr(), stream=stream, want_stats=True)
+                extras["certificate_audit"] = {"spp": aspp, "second_tree_answers_audited": int(sa.certificate_audited), "differing_from_the_reference_walk": int(sa.certificate_audit_mismatches),
+                                               "certificate_fallbacks": int(sa.certificate_fallbacks), "rays": int(sa.rays),
+                                               "what": "counting build: every answer of the second tree (hit or miss) is also walked on the reference tree and compared -- triangle and the bit "
+                                                       "patterns of t, u, v; blocked-or-not for any-hit shadow rays"}
+                ctx.set_camera_sun(cam, tuple(fr.sun_dir_model))
+            except Exception as e:  # noqa: BLE001
+                extras["certificate_audit"] = {"error": str(e)[:200]}
         # The same frame with every ray on the reference tree (DSRT_TUNE_REFERENCE_WALK): what the certified second tree buys, and the plain walk's own speed.
         if certified:
             try:

@@ -88,7 +88,7 @@ class DsrtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("waves_launched", C.c_int), ("device_flags", C.c_uint32), ("lds_stack_entries", C.c_int)] + \
                [(n, C.c_uint64) for n in ("samples", "rays", "primary_hits", "box_fetches", "nodes_entered", "internal_entered", "tri_tests",
                                           "hit_updates", "sphere_tests", "shaded_hits", "tex_fetches", "stack_spills", "max_stack",
-                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12", "tiles_total", "tiles_culled", "wave_ticks", "certificate_fallbacks")] + \
+                                          "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12", "tiles_total", "tiles_culled", "wave_ticks", "certificate_fallbacks", "certificate_audited", "certificate_audit_mismatches")] + \
                [(n, C.c_float) for n in ("heavy_queue_empty_ms", "light_queue_empty_ms", "last_wave_exit_ms")] + [("certified_tree_used", C.c_int)]
 
 

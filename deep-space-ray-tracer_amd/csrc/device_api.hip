@@ -393,7 +393,7 @@ int install_scene(DsrtContext* ctx, const GPUScene& host_layout) {
     return DSRT_OK;
 }
 
-constexpr size_t kQueueLightWord = 64;                       // the light queue's counter: its own cache line, past the counters
+constexpr size_t kQueueLightWord = 96;                       // the light queue's counter: its own cache line, past the counters
 constexpr size_t kCtrlWords = kQueueLightWord + 16;
 static_assert(4 + 2 * (size_t)kNumCounters <= kQueueLightWord, "counters overlap the second queue word");
 
@@ -718,6 +718,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         else ok = near_enough(ctx->camera.origin);
         a.accel = ok ? 1 : 0;
     }
+    a.audit = a.accel && desc->collect_counters == 3 ? 1 : 0;
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
@@ -856,6 +857,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         stats->idle_at_leaf = cnt[C_IDLE_AT_LEAF]; stats->idle_waiting = cnt[C_IDLE_WAITING]; stats->idle_done = cnt[C_IDLE_DONE];
         stats->wave_ticks = cnt[C_WAVE_TICKS];
         stats->certificate_fallbacks = cnt[C_CERT_FALLBACKS];
+        stats->certificate_audited = cnt[C_AUDITED]; stats->certificate_audit_mismatches = cnt[C_AUDIT_MISMATCHES];
         stats->certified_tree_used = a.accel;
         {   // time marks relative to the first wave's start, in ms (0 when the mark was never passed)
             const double t0 = (double)~cnt[C_T_FIRST];

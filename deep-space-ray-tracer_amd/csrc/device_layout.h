@@ -150,13 +150,14 @@ struct RenderArgs {
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
     int       deal_leaves;     // 1: a parked leaf's second pair record is evaluated by a lane that is not at a leaf (render_kernel.hip, phase L)
     int       accel;           // 1: rays start on the certified second tree and fall back to the reference tree when the certificate fails (path_machine.h)
+    int       audit;           // counting build: 1 = every answer of the second tree is also walked on the reference tree and compared (path_machine.h, CERTIFICATE AUDIT)
 };
 
 // order matches the DsrtStats tail in include/dsrt.h
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
                C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
-               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_CERT_FALLBACKS, C_WAVE_TICKS,
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_CERT_FALLBACKS, C_AUDITED, C_AUDIT_MISMATCHES, C_WAVE_TICKS,
                C_T_FIRST, C_T_HEAVY_EMPTY, C_T_LIGHT_EMPTY, C_T_LAST,      // wall-clock marks (100 MHz ticks), kept as maxima: the first three of ~t
                kNumCounters };
 

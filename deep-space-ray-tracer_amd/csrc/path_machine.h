@@ -39,7 +39,7 @@ constexpr uint32_t kAwait = 1u << 8;
 // The certified second tree (args.accel; device_api.hip: pack_scene).  A ray starts on the second tree with its distance culling relaxed by kCullRelax; when its walk
 // ends, the CERTIFICATE decides whether the answer is provably the reference walk's (advance_step), and if not the same ray walks the reference tree.
 //              bit 10 kOnRef: this ray is (re-)walking the reference tree: its answer is final;  bit 11 kTie: the last accept on the second tree was an equality accept
-constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11;
+constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11, kAudit = 1u << 12;   // (kAudit: counting build, RenderArgs::audit -- this ray's certified answer is being checked against the reference walk)
 constexpr float kCullRelax = 1.0f + 1.0f / 1024.0f;
 constexpr uint32_t kHot = 1u << 9;           // rng_mode 0: the pixel this lane is working on belongs to a heavy tile (its wave asks for issue priority)
 
@@ -65,6 +65,7 @@ struct Lane {
     F3 ro = {0, 0, 0}, rd = {0, 0, 1}, rinv = {0, 0, 0};
     int cur = kRefNone, sp = 0, hit_slot = -1;
     float closest = kTMax, hit_u = 0.0f, hit_v = 0.0f;
+    int audit_orig = -1; float audit_t = 0.0f, audit_u = 0.0f, audit_v = 0.0f;     // counting build, certificate audit: the second tree's answer while the reference tree is walked
     float cull = kTMax;                          // what BOXES are culled against: `closest` itself on the reference tree, closest * kCullRelax on the second tree
     float relax = 1.0f;                          // cull = closest * relax
     uint32_t steps = 0;
@@ -184,25 +185,48 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
     // A ray that found nothing found nothing: the second tree's walk is conservative (boxes widened at upload, distance culling relaxed by kCullRelax).
     // A ray that fails any condition walks the reference tree -- the same ray, from the root, with the reference's own culling -- and that answer is final.
     if (args.accel) {
-        if ((state == ST_SHADE || state == ST_SHADOW_DONE) && hit_slot >= 0 && !(ln.aux & kOnRef)) {
-            const float4* cb = S.tri_cert + (size_t)hit_slot * 2;
-            const float4 c0 = cb[0], c1 = cb[1];
-            float t_entry;
-            const bool certified = slab(mk(c0.x, c0.y, c0.z), mk(c0.w, c1.x, c1.y), ro, rinv, closest, t_entry) && !(ln.aux & kTie) &&
-                                   rd.x != 0.0f && rd.y != 0.0f && rd.z != 0.0f;
-            if (!certified) {
-                if (COUNT) c[C_CERT_FALLBACKS]++;
+        // CERTIFICATE AUDIT (counting build, DsrtRenderDesc.collect_counters = 3): every answer of the second tree -- certified hits and misses alike -- is ALSO walked on the
+        // reference tree, the two answers are compared (triangle, and the bit patterns of t, u, v; for an any-hit shadow ray: blocked or not), differences are counted
+        // (DsrtStats.certificate_audit_mismatches: must be 0) and the reference walk's answer is the one used.  What the certificate claims, checked ray by ray.
+        const bool ended = state == ST_SHADE || state == ST_SHADOW_DONE;
+        if (COUNT && ended && (ln.aux & kAudit) && (ln.aux & kOnRef)) {          // the reference walk of an audited ray has ended: compare
+            ln.aux &= ~kAudit;
+            bool same;
+            if (ANYHIT && state == ST_SHADOW_DONE) same = (hit_slot >= 0) == (ln.audit_orig >= 0);
+            else if (hit_slot < 0) same = ln.audit_orig < 0;
+            else same = __float_as_int(S.tri_shade[(size_t)hit_slot * 3 + 2].w) == ln.audit_orig && __float_as_uint(closest) == __float_as_uint(ln.audit_t) &&
+                        __float_as_uint(hit_u) == __float_as_uint(ln.audit_u) && __float_as_uint(hit_v) == __float_as_uint(ln.audit_v);
+            if (!same) c[C_AUDIT_MISMATCHES]++;
+        } else if (ended && !(ln.aux & kOnRef)) {
+            bool certified = true;
+            if (hit_slot >= 0) {
+                const float4* cb = S.tri_cert + (size_t)hit_slot * 2;
+                const float4 c0 = cb[0], c1 = cb[1];
+                float t_entry;
+                certified = slab(mk(c0.x, c0.y, c0.z), mk(c0.w, c1.x, c1.y), ro, rinv, closest, t_entry) && !(ln.aux & kTie) &&
+                            rd.x != 0.0f && rd.y != 0.0f && rd.z != 0.0f;
+            }
+            const bool audit = COUNT && args.audit != 0 && certified;
+            if (!certified || audit) {
+                if (COUNT && !certified) c[C_CERT_FALLBACKS]++;
+                if (COUNT && audit) {
+                    c[C_AUDITED]++;
+                    ln.audit_orig = hit_slot >= 0 ? __float_as_int(S.tri_shade[(size_t)hit_slot * 3 + 2].w) : -1;
+                    ln.audit_t = closest; ln.audit_u = hit_u; ln.audit_v = hit_v;
+                    ln.aux |= kAudit;
+                }
                 ln.aux = (ln.aux | kOnRef) & ~kTie;
                 closest = kTMax; ln.cull = kTMax; ln.relax = 1.0f;
                 hit_slot = -1;
                 sp = 0;
                 steps = 0;
+                float t_entry;
                 // the head of bvh_hit_closest :394-410 on the reference tree; a miss of its root box leaves the ray in ST_SHADE / ST_SHADOW_DONE without a hit
                 if (S.root_ref != kRefNone && slab(ld3(S.root_lo), ld3(S.root_hi), ro, rinv, closest, t_entry)) { cur = S.root_ref; state += ST_TRAV_CLOSEST - ST_SHADE; }
+                else if (COUNT && (ln.aux & kAudit)) { ln.aux &= ~kAudit; if (ln.audit_orig >= 0) c[C_AUDIT_MISMATCHES]++; }      // (the reference misses its root box: its answer is "no hit", now)
             }
         }
     }
-
     if (state == ST_SHADOW_DONE) {
         // blocked = scene_hit(shadow_ray) :816: BVH result, then the spheres
         bool blocked = hit_slot >= 0;

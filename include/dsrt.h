@@ -217,7 +217,9 @@ typedef struct DsrtRenderDesc {
     int      shard_rank;            /* this process renders tiles t with t % shard_count == shard_rank */
     int      shard_count;           /* 0 or 1 -> whole image                                      */
     int      collect_counters;      /* 1 -> counting build of the kernel (fills DsrtStats); 2 -> counting build WITHOUT the any-hit
-                                       shadow-ray early-out, whose counters equal the reference traversal's exactly */
+                                       shadow-ray early-out, whose counters equal the reference traversal's exactly; 3 -> counting build
+                                       with the CERTIFICATE AUDIT: when the certified second tree is in use, every one of its answers is also walked
+                                       on the reference tree and compared (DsrtStats.certificate_audited / certificate_audit_mismatches) */
     int      checked;               /* 1 -> bounds-checked build of the kernel (tests / first runs) */
     int      stack_entries;         /* LDS short-stack entries per lane: 0 or 8 (the only size built)  */
     int      tune[4];               /* scheduling knobs, 0 = default: {min_walk_iters, advance_budget, leaf_ratio4, flags}.  None of them
@@ -269,6 +271,8 @@ typedef struct DsrtStats {
     uint64_t wave_ticks;
     /* counting build, certified second tree in use: BVH queries whose certificate failed and which were walked again on the reference tree */
     uint64_t certificate_fallbacks;
+    /* collect_counters = 3 (the CERTIFICATE AUDIT): answers of the second tree that were also walked on the reference tree, and how many of them differed (must be 0) */
+    uint64_t certificate_audited, certificate_audit_mismatches;
     /* counting build, ms after the first wave started: the heavy / the light work queue handed out its last item, the last wave left */
     float    heavy_queue_empty_ms, light_queue_empty_ms, last_wave_exit_ms;
     int      certified_tree_used;   /* 1: the rays of this launch started on the certified second tree (dsrt_ctx_set_certified_tree) */

@@ -152,3 +152,49 @@ def test_certified_tree_in_shards_batches_far_cameras_and_rng_mode_1(dsrt, cert_
     a, _, _ = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1))
     b, _, _ = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, rng_mode=1, tune=(0, 0, 0, 64)))
     assert np.array_equal(a, b) and a.max() > 0
+
+
+def test_certificate_audit_every_answer_of_the_second_tree_against_the_reference_walk(dsrt, cert_ctx, oracle, tmp_path):
+    """collect_counters = 3: the counting build walks EVERY answer of the second tree -- certified hits and misses -- on the reference tree as well and compares them ray by
+    ray (triangle, bit patterns of t, u, v; blocked-or-not for any-hit shadow rays).  The certificate's claim, checked directly: audited > 0, mismatches == 0, on the parity
+    scenes, the quirks mesh, the 100 k station and the bench's 1 M-triangle mesh (1080p x 8 samples: 30 M rays).  Then the negative control: with one box of the second tree
+    made empty (the test hook overwrites a word of its root record) the second tree loses geometry -- the audit must SEE that (mismatches > 0), and because the audit uses
+    the reference walk's answers the image is still the oracle's."""
+    import struct
+    total_audited = 0
+    for name in ("station_near", "mixed", "textured"):
+        world, cam_args, spp = CASES[name]
+        hs = load_world(dsrt, world)
+        W, H, depth = cam_args[3], cam_args[4], cam_args[5]
+        scene = hs.view(dsrt.camera_look_at(cam_args[0], cam_args[1], cam_args[2], W, H, spp, depth), SUN)
+        want, _, _ = oracle.render(scene, W, H)
+        cert_ctx.upload(scene)
+        rgb, _, st = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=3))
+        assert st.certified_tree_used == 1 and st.certificate_audited > 1000 and st.certificate_audit_mismatches == 0, (name, st.certificate_audited, st.certificate_audit_mismatches)
+        assert np.array_equal(rgb, want), name
+        total_audited += st.certificate_audited
+    quirks = next(j for j in J.fuzz_jobs() if j["world"] == "quirks" and j["W"] * j["H"] > 2000)
+    _, _, st = _job_image(dsrt, cert_ctx, {}, quirks, collect_counters=3)
+    assert st.certificate_audit_mismatches == 0 and st.certificate_audited > 0
+    poses = dsrt.read_pose_file(J.POSES)
+    fr = dsrt.pose_to_frame(poses[98])
+    for tris, W, H, spp in ((100000, 640, 360, 8), (1000000, 1920, 1080, 8)):
+        hs = dsrt.HostScene().add_obj(J.station_obj(tris, tmp_path))
+        hs.build_bvh()
+        scene = hs.view(dsrt.frame_camera(fr, 40.0, W, H, spp, 50), tuple(fr.sun_dir_model))
+        cert_ctx.upload(scene)
+        rgb, _, st = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, collect_counters=3))
+        plain, _, _ = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, tune=(0, 0, 0, 64)))
+        assert st.certificate_audit_mismatches == 0, (tris, st.certificate_audited, st.certificate_audit_mismatches)
+        assert st.certificate_audited >= st.rays - st.certificate_fallbacks - 8 and st.certificate_audited > 0.9 * W * H * spp
+        assert np.array_equal(rgb, plain)
+        total_audited += st.certificate_audited
+    assert total_audited > 25_000_000
+    # negative control on the 1 M mesh (still resident): the left child box of the second tree's root made empty -> geometry lost on the second tree -> the audit reports it
+    old = cert_ctx.poke_node_word(0, struct.unpack("<I", struct.pack("<f", 1.0e30))[0])            # record 0 = the second tree's root; word 0 = L.lo.x
+    try:
+        rgb2, _, st2 = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, 50, collect_counters=3))
+    finally:
+        cert_ctx.poke_node_word(0, old)
+    assert st2.certificate_audit_mismatches > 1000, st2.certificate_audit_mismatches
+    assert np.array_equal(rgb2, plain), "the audit renders with the reference walk's answers: a broken second tree must not change the image"

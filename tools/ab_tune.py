@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shards", type=int, default=1)
     ap.add_argument("--bvh", type=str, default="median")
+    ap.add_argument("--lambertian", action="store_true", help="the same mesh with every material made Lambertian (Ks 0, d 1): a scene that qualifies for the LEAN kernels")
     ap.add_argument("--certified", action="store_true", help="upload with the certified second tree (dsrt_ctx_set_certified_tree); a sixth config field of 1 then renders on the "
                                                               "plain reference walk (DSRT_TUNE_REFERENCE_WALK), e.g. 0:0 0:0:0:0:0:1")
     a = ap.parse_args()
@@ -33,7 +34,21 @@ def main():
     from dsrt_amd import meshgen
     obj = f"/tmp/dsrt_bench_station_v{meshgen.VERSION}_{a.tris}.obj"
     if not os.path.exists(obj):
-        meshgen.write_obj(meshgen.build_station(a.tris), obj)
+        meshgen.write_obj(meshgen.build_station(a.tris), obj, mtl_name=os.path.basename(obj)[:-4] + ".mtl")
+    if a.lambertian:
+        lean = obj[:-4] + "_lambertian.obj"
+        if not os.path.exists(lean):
+            import re
+            mtl_src = [l.split()[1] for l in open(obj) if l.startswith("mtllib")]
+            text = open(os.path.join(os.path.dirname(obj), mtl_src[0])).read() if mtl_src else ""
+            text = re.sub(r"^Ks .*$", "Ks 0.0 0.0 0.0", text, flags=re.M)
+            text = re.sub(r"^d .*$", "d 1.0", text, flags=re.M)
+            text = re.sub(r"^Ni .*$", "Ni 1.0", text, flags=re.M)
+            open(lean[:-4] + ".mtl", "w").write(text)
+            with open(obj) as src, open(lean, "w") as dst:
+                for l in src:
+                    dst.write(f"mtllib {os.path.basename(lean)[:-4]}.mtl\n" if l.startswith("mtllib") else l)
+        obj = lean
     hs = d.HostScene().add_obj(obj)
     hs.build_bvh(a.bvh)
     poses = d.read_pose_file(os.path.join(ROOT, "tests", "golden", "rendezvous_1s_dt0_01s.txt"))

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--tune", type=str, default="0:0:0:0")
     ap.add_argument("--counters", action="store_true")
+    ap.add_argument("--certified", action="store_true", help="upload with the certified second tree (dsrt_ctx_set_certified_tree)")
     ap.add_argument("--ranks", type=str, default="", help="which ranks of the share to time (default: first, middle, last)")
     a = ap.parse_args()
     import torch
@@ -38,6 +39,8 @@ def main():
     W, H, spp = a.width, a.height, a.spp
     cam = d.frame_camera(fr, 40.0, W, H, spp, 50)
     ctx = d.Context(0)
+    if a.certified:
+        ctx.set_certified_tree(True)
     ctx.upload(hs.view(cam, tuple(fr.sun_dir_model)))
     stream = torch.cuda.current_stream().cuda_stream
     base = None
@@ -62,7 +65,7 @@ def main():
                      "queues_empty_heavy_light_last_exit_ms": [round(sc.heavy_queue_empty_ms, 1), round(sc.light_queue_empty_ms, 1), round(sc.last_wave_exit_ms, 1)], "waves": sc.waves_launched, "mean_wave_residency": round(sc.wave_ticks / 1e5 / max(1e-9, sc.kernel_ms) / max(1, sc.waves_launched), 3)}
         worst = max(times)
         base = worst if base is None else base
-        print(json.dumps({"frame": a.frame, "rng_mode": a.rng, "bvh": a.bvh, "shards": n, "tune": a.tune, "ranks_timed": ranks, "kernel_ms": [round(t, 2) for t in times],
+        print(json.dumps({"frame": a.frame, "certified_tree": bool(a.certified), "rng_mode": a.rng, "bvh": a.bvh, "shards": n, "tune": a.tune, "ranks_timed": ranks, "kernel_ms": [round(t, 2) for t in times],
                           "speedup_vs_1": round(base / worst, 2), "efficiency": round(base / worst / n, 3), **extra}), flush=True)
 
 
