@@ -1066,6 +1066,11 @@ DsrtContext* dropin_context() {
 }
 }  // namespace
 
+int dsrt_dropin_has_certified_tree(void) {
+    std::lock_guard<std::mutex> lock(g_dropin_mutex);
+    return g_dropin_ctx && g_dropin_ctx->scene && g_dropin_ctx->scene->valid && g_dropin_ctx->scene->has_second_tree ? 1 : 0;
+}
+
 int dsrt_build_gpu_scene(const DsrtHostScene* hs, const GPUCamera* cam, const float sun_dir_model[3], GPUScene* out) {
     return dsrt::guarded("dsrt_build_gpu_scene", [&]() -> int {
     if (!hs || !cam || !out) { set_error("dsrt_build_gpu_scene: null argument"); return DSRT_ERR_INVALID; }
@@ -1124,7 +1129,10 @@ static void gpu_render_scene_body(const GPUScene* scene, int width, int height) 
     if (!ctx) { std::fprintf(stderr, "gpu_render_scene: %s\n", dsrt_last_error()); return; }
     SceneFingerprint fp;
     if (fingerprint_device_scene(*scene, fp) != DSRT_OK) { std::fprintf(stderr, "gpu_render_scene: %s\n", dsrt_last_error()); return; }
-    if (ctx->scene && ctx->scene->valid && fp == g_dropin_fp) {
+    // The reference's entry point has nowhere to ask for the certified second tree either: DSRT_CERTIFIED_TREE=1, looked at on every call here (the one context of the
+    // drop-in lives as long as the process); a change of the variable re-converts the scene.
+    { const char* e = std::getenv("DSRT_CERTIFIED_TREE"); ctx->want_second_tree = e && e[0] == '1'; }
+    if (ctx->scene && ctx->scene->valid && fp == g_dropin_fp && ctx->scene->has_second_tree == (ctx->want_second_tree && ctx->scene->view.root_ref != kRefNone)) {
         // same geometry, materials and textures as the previous call: only the per-frame part of the header is taken over
         ctx->camera = scene->camera;
         ctx->sun_dir = scene->sun_dir; ctx->sun_radiance = scene->sun_radiance; ctx->sun_enabled = scene->sun_enabled ? 1 : 0;

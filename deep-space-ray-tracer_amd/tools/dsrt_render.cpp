@@ -26,7 +26,7 @@ static int fail(const char* what) {
 int main(int argc, char** argv) {
     std::string pose_file, out_dir = "output", obj;
     int width = 800, height = 450, spp = 1000, depth = 50, first = 0, count = -1, rng_mode = 0, math_mode = 0;
-    bool sah = false, lbvh = false, png = false, strict_textures = false;
+    bool sah = false, lbvh = false, png = false, strict_textures = false, certified = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* {
@@ -46,10 +46,11 @@ int main(int argc, char** argv) {
         else if (a == "--bvh") { const std::string k = next("--bvh"); sah = k == "sah"; lbvh = k == "lbvh"; }      // lbvh: built on the GPU (milliseconds), non-parity like sah
         else if (a == "--rng-mode") rng_mode = std::atoi(next("--rng-mode"));
         else if (a == "--reference-math") math_mode = 1;          // sinf / cosf / powf from the device math library: the reference's own kernel's bytes on this GPU (include/dsrt.h)
+        else if (a == "--certified-tree") certified = true;        // rays walk the certified second tree: the reference's bytes, a third fewer node visits (include/dsrt.h)
         else if (a == "--strict-textures") strict_textures = true;  // refuse a mesh whose texture maps this library cannot decode (include/dsrt.h)
         else if (a == "--png") png = true;                          // frames as PNG instead of PPM (the reference converts with ImageMagick)
         else if (a == "--upscale") std::fprintf(stderr, "dsrt_render: --upscale is not supported (post-process outside this library)\n");
-        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah|lbvh] [--rng-mode 0|1] [--reference-math] [--fast] [--png] [--strict-textures]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: dsrt_render --obj mesh.obj [--input_txt poses.txt] [--output_dir dir] [--width W --height H --spp N --depth D] [--frame i --frames n] [--bvh median|sah|lbvh] [--rng-mode 0|1] [--reference-math] [--certified-tree] [--fast] [--png] [--strict-textures]\n"); return 2; }
     }
     if (obj.empty()) { std::fprintf(stderr, "dsrt_render: --obj is required\n"); return 2; }
     mkdir(out_dir.c_str(), 0777);
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
 
     DsrtContext* ctx = nullptr;
     if (dsrt_ctx_create(0, &ctx) != DSRT_OK) return fail("creating the device context");
+    if (certified && dsrt_ctx_set_certified_tree(ctx, 1) != DSRT_OK) return fail("asking for the certified second tree");
     // The reference's loop renders frame after frame (src/main.cpp:310-431).  Here the poses of a run are rendered as batch launches
     // (dsrt_render_batch_to_host: up to 32 frames as ONE pool of work, include/dsrt.h) and written out in pose order afterwards: each
     // frame's image is byte for byte what a launch of its own would give, the run is simply not held up by every frame's tail.

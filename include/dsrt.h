@@ -185,6 +185,7 @@ int  dsrt_ctx_device(const DsrtContext* ctx);
  * (about as much again as the scene) and the SAH build at upload (0.2 s per million triangles).  DSRT_TUNE_REFERENCE_WALK renders without it. */
 int  dsrt_ctx_set_certified_tree(DsrtContext* ctx, int on);
 int  dsrt_ctx_has_certified_tree(const DsrtContext* ctx);
+int  dsrt_dropin_has_certified_tree(void);     /* the same question about the scene the drop-in gpu_render_scene converted last (it looks at DSRT_CERTIFIED_TREE on every call) */
 
 /* Upload + re-layout for the GPU (once per scene, not per frame).  `scene` holds HOST pointers in the
  * reference layouts (as from dsrt_host_scene_view); its camera/params/sun are recorded as the current frame.

@@ -198,3 +198,43 @@ def test_certificate_audit_every_answer_of_the_second_tree_against_the_reference
         cert_ctx.poke_node_word(0, old)
     assert st2.certificate_audit_mismatches > 1000, st2.certificate_audit_mismatches
     assert np.array_equal(rgb2, plain), "the audit renders with the reference walk's answers: a broken second tree must not change the image"
+
+
+def test_certified_tree_through_the_environment_reaches_the_drop_in_and_the_multi_gpu_host(dsrt, oracle, tmp_path, monkeypatch):
+    """DSRT_CERTIFIED_TREE=1: contexts the library creates ITSELF -- the drop-in gpu_render_scene's and dsrt_multi_*'s -- build and use the second tree.  The drop-in's
+    file must be the plain run's file, byte for byte (header included); the multi-GPU host's frame (two ranks on the one GPU there is) the oracle's image."""
+    import ctypes as C
+    name = "station_near"
+    world, cam_args, spp = CASES[name]
+    hs = load_world(dsrt, world)
+    W, H, depth = cam_args[3], cam_args[4], cam_args[5]
+    cam = dsrt.camera_look_at(cam_args[0], cam_args[1], cam_args[2], W, H, spp, depth)
+    want, _, _ = oracle.render(hs.view(cam, SUN), W, H)
+    monkeypatch.setenv("DSRT_CERTIFIED_TREE", "1")
+    ctx = dsrt.Context(0)                                   # (created under the variable: the option is on without the call)
+    ctx.upload(hs.view(cam, SUN))
+    assert ctx.has_certified_tree
+    rgb, _, st = ctx.render_to_host(dsrt.make_desc(W, H, spp, depth))
+    assert st.certified_tree_used == 1 and np.array_equal(rgb, want)
+    ctx.close()
+    m = dsrt.Multi([0, 0])
+    m.upload(hs.view(cam, SUN))
+    img, _, _ = m.render_frame(dsrt.make_desc(W, H, spp, depth), cam, SUN)
+    assert np.array_equal(np.asarray(img).reshape(H, W, 3), want)
+    m.close()
+    # the drop-in entry point: its own context is created on first use
+    dev = dsrt.GPUScene()
+    assert dsrt.lib.dsrt_build_gpu_scene(hs._h, C.byref(cam), (C.c_float * 3)(*SUN), C.byref(dev)) == 0, dsrt.lib.dsrt_last_error()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        dsrt.lib.gpu_render_scene(C.byref(dev), W, H)
+        data = open("image_gpu.ppm", "rb").read()
+        assert dsrt.lib.dsrt_dropin_has_certified_tree() == 1
+        monkeypatch.delenv("DSRT_CERTIFIED_TREE")
+        dsrt.lib.gpu_render_scene(C.byref(dev), W, H)           # the variable gone: the same scene is converted again, without the second tree
+        assert dsrt.lib.dsrt_dropin_has_certified_tree() == 0 and open("image_gpu.ppm", "rb").read() == data
+    finally:
+        os.chdir(cwd)
+        dsrt.lib.dsrt_free_gpu_scene(C.byref(dev))
+    assert data == b"P6\n%d %d\n255\n" % (W, H) + want.tobytes()

@@ -443,6 +443,12 @@ def test_cli_renders_pose_frames_like_the_library(dsrt, oracle, tmp_path):
         pos += 12 + n
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + W * 3)
     assert np.array_equal(rows[:, 1:].reshape(H, W, 3), want)
+    # --certified-tree: the same bytes as the plain run
+    out4 = tmp_path / "certified"
+    r = subprocess.run(common + ["--output_dir", str(out4), "--certified-tree"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f in sorted(os.listdir(out)):
+        assert open(out4 / f, "rb").read() == open(out / f, "rb").read(), f
     # fast mode: runs, right size, statistically the same picture
     out3 = tmp_path / "fast"
     r = subprocess.run(common + ["--output_dir", str(out3), "--fast"], capture_output=True, text=True, timeout=300)
