@@ -30,7 +30,9 @@ struct Box {
     }
 };
 
-constexpr int kBins = 32;
+constexpr int kMaxBins = 128;
+static int g_bins = 32;                     // development override: DSRT_SAH_BINS (4..128)
+static int g_sweep_below = 0;               // development override: DSRT_SAH_SWEEP -- ranges of at most this many triangles are split by an exact sweep over the sorted centroids
 
 constexpr int kParallelMin = 1 << 15;       // ranges smaller than this are not worth a thread
 
@@ -65,13 +67,33 @@ struct SahBuilder {
         const int count = end - start;
         if (count <= kLeafMax) return self;
 
+        int sweep_mid = -1;
+        if (g_sweep_below > 0 && count <= g_sweep_below) {
+            // (development knob) small ranges: every one of the n - 1 splits of the centroids sorted along each axis, not just the bin boundaries
+            std::vector<int> idx(order.begin() + start, order.begin() + end), best_idx;
+            std::vector<double> right((size_t)count);
+            double best = std::numeric_limits<double>::infinity();
+            for (int a = 0; a < 3; ++a) {
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return centroid[3 * (size_t)x + a] < centroid[3 * (size_t)y + a]; });
+                Box acc; acc.clear();
+                for (int i = count - 1; i >= 1; --i) { acc.grow(tri_box[idx[(size_t)i]]); right[(size_t)i] = acc.half_area(); }
+                acc.clear();
+                for (int i = 0; i + 1 < count; ++i) {
+                    acc.grow(tri_box[idx[(size_t)i]]);
+                    const double cost = acc.half_area() * (i + 1) + right[(size_t)i + 1] * (count - i - 1);
+                    if (cost < best) { best = cost; sweep_mid = start + i + 1; best_idx = idx; }
+                }
+            }
+            if (sweep_mid > 0) std::copy(best_idx.begin(), best_idx.end(), order.begin() + start);
+        }
         // best binned split over the three axes
         double best_cost = std::numeric_limits<double>::infinity();
         int best_axis = -1, best_bin = -1;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && sweep_mid < 0; ++a) {
             const float extent = cbox.hi[a] - cbox.lo[a];
             if (!(extent > 0.0f)) continue;
-            Box bin_box[kBins]; int bin_n[kBins];
+            const int kBins = g_bins;
+            Box bin_box[kMaxBins]; int bin_n[kMaxBins];
             for (int b = 0; b < kBins; ++b) { bin_box[b].clear(); bin_n[b] = 0; }
             const float scale = (float)kBins / extent;
             for (int i = start; i < end; ++i) {
@@ -80,7 +102,7 @@ struct SahBuilder {
                 bin_box[b].grow(tri_box[order[i]]);
                 bin_n[b]++;
             }
-            double right_area[kBins]; int right_n[kBins];
+            double right_area[kMaxBins]; int right_n[kMaxBins];
             Box acc; acc.clear(); int n = 0;
             for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); n += bin_n[b]; right_area[b] = acc.half_area(); right_n[b] = n; }
             acc.clear(); n = 0;
@@ -92,10 +114,13 @@ struct SahBuilder {
             }
         }
         int mid;
-        if (best_axis < 0) {
+        if (sweep_mid > 0) {
+            mid = sweep_mid;
+        } else if (best_axis < 0) {
             // every centroid coincides: nothing to sort by; split the range in half by position (keeps leaves small)
             mid = (start + end) / 2;
         } else {
+            const int kBins = g_bins;
             const float lo = cbox.lo[best_axis], scale = (float)kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
             const float* c = centroid.data();
             const int axis = best_axis, bin = best_bin;
@@ -153,6 +178,8 @@ int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8
     height_out = 0;
     if (n == 0) return DSRT_OK;
     if (n > (size_t)1 << 28) { dsrt::set_error("more than 2^28 triangles"); return DSRT_ERR_INVALID; }
+    if (const char* e = std::getenv("DSRT_SAH_BINS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 4 && v <= kMaxBins) g_bins = (int)v; }
+    if (const char* e = std::getenv("DSRT_SAH_SWEEP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 4096) g_sweep_below = (int)v; }
     std::vector<Box> tri_box(n);
     std::vector<float> centroid(3 * n);
     for (size_t i = 0; i < n; ++i) {
