@@ -287,7 +287,16 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
             int height2 = 0;
             int rc = build_sah_tree(h.triangles, (size_t)N, extent > 0.0f ? extent * (1.0f / 65536.0f) : 1.0e-6f, unreachable.data(), nodes2, order2, height2, second_tree_leaf_max());
             if (rc != DSRT_OK) return rc;
-            if (!nodes2.empty()) {
+            // Rays also start on SPHERES (bounces, shadow rays): one whose surface reaches beyond 30 extents of the mesh puts origins where the widening above no longer
+            // covers the rounding of (box - origin) -- such a scene keeps the reference tree only.
+            bool origins_near = true;
+            for (int i = 0; i < h.num_spheres && origins_near; ++i) {
+                const GPUSphere& sp = h.spheres[i];
+                const double dx = (double)sp.center.x - 0.5 * ((double)root.bbox_min.x + root.bbox_max.x), dy = (double)sp.center.y - 0.5 * ((double)root.bbox_min.y + root.bbox_max.y),
+                             dz = (double)sp.center.z - 0.5 * ((double)root.bbox_min.z + root.bbox_max.z);
+                origins_near = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)sp.radius) <= 30.0 * (double)extent;
+            }
+            if (!nodes2.empty() && origins_near) {
                 if ((rc = pack_tree(h, nodes2.data(), (int)nodes2.size(), order2.data(), (int)order2.size(), textured, leaf_box.data(), arr, acc_tree))) return rc;
                 out.has_second_tree = true;
                 out.scene_extent = extent;
@@ -700,7 +709,7 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     a.spill = ctx->spill.p;
     a.spill_stride = (uint32_t)lanes;
     a.spill_entries = spill_entries;
-    a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;
+    a.min_walk_iters = desc->tune[0] > 0 ? desc->tune[0] : 64;      // (192 when the rays walk the certified second tree: set below, once a.accel is known)
     a.advance_budget = desc->tune[1] > 0 ? desc->tune[1] : 12;
     a.leaf_ratio4 = desc->tune[2] > 0 ? desc->tune[2] : 10;            // (16 until the node loop looked at its votes every other iteration: profiles/r03/ab_loop_knobs_after_unroll.jsonl)
     a.deal_leaves = (xp & 128u) ? 0 : 1;
@@ -719,6 +728,9 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         a.accel = ok ? 1 : 0;
     }
     a.audit = a.accel && desc->collect_counters == 3 ? 1 : 0;
+    // Walks of the second tree are a third shorter, so an advance pass is dearer against a node iteration than on the reference tree: the traverse phase stays three times
+    // longer before it yields (interleaved medians, near frame: 760 -> 741 ms in rng_mode 0, 734 -> 701 in rng_mode 1; the reference walk gains nothing from it).
+    if (a.accel && desc->tune[0] <= 0) a.min_walk_iters = 192;
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).

@@ -40,7 +40,10 @@ constexpr uint32_t kAwait = 1u << 8;
 // ends, the CERTIFICATE decides whether the answer is provably the reference walk's (advance_step), and if not the same ray walks the reference tree.
 //              bit 10 kOnRef: this ray is (re-)walking the reference tree: its answer is final;  bit 11 kTie: the last accept on the second tree was an equality accept
 constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11, kAudit = 1u << 12;   // (kAudit: counting build, RenderArgs::audit -- this ray's certified answer is being checked against the reference walk)
-constexpr float kCullRelax = 1.0f + 1.0f / 1024.0f;
+#ifndef DSRT_CULL_RELAX_DIV
+#define DSRT_CULL_RELAX_DIV 1024.0f
+#endif
+constexpr float kCullRelax = 1.0f + 1.0f / DSRT_CULL_RELAX_DIV;
 constexpr uint32_t kHot = 1u << 9;           // rng_mode 0: the pixel this lane is working on belongs to a heavy tile (its wave asks for issue priority)
 
 // Hand-off between two LANES of one wave through LDS (request table, ray, answer word).  The lanes of a wave execute in lockstep and
