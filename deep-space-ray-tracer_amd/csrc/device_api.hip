@@ -296,7 +296,9 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
                              dz = (double)sp.center.z - 0.5 * ((double)root.bbox_min.z + root.bbox_max.z);
                 origins_near = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)sp.radius) <= 30.0 * (double)extent;
             }
-            if (!nodes2.empty() && origins_near) {
+            // (both trees share one array of node records addressed by a 32-bit byte offset: a scene too big for two trees in it keeps the reference tree only)
+            const bool fits = nodes2.size() / 2 + (size_t)M / 2 + 2 * (size_t)kRefBias < ((size_t)1 << 26) && (order2.size() + (size_t)N) / 2 + nodes2.size() / 2 + (size_t)M / 2 < ((size_t)1 << 28);
+            if (!nodes2.empty() && origins_near && fits) {
                 if ((rc = pack_tree(h, nodes2.data(), (int)nodes2.size(), order2.data(), (int)order2.size(), textured, leaf_box.data(), arr, acc_tree))) return rc;
                 out.has_second_tree = true;
                 out.scene_extent = extent;
