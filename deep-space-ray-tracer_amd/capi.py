@@ -106,7 +106,7 @@ assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.ite
 ABI_VERSION = 7
 
 EXPORTS = [
-    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word", "dsrt_ctx_set_certified_tree", "dsrt_ctx_has_certified_tree", "dsrt_dropin_has_certified_tree",
+    "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word", "dsrt_ctx_set_certified_tree", "dsrt_ctx_has_certified_tree", "dsrt_dropin_has_certified_tree", "dsrt_host_scene_second_tree_probe",
     "dsrt_host_scene_create", "dsrt_host_scene_destroy", "dsrt_host_scene_add_obj", "dsrt_host_scene_add_world_file",
     "dsrt_host_scene_add_arrays", "dsrt_host_scene_add_texture_file", "dsrt_host_scene_build_bvh", "dsrt_host_scene_build_bvh_sah", "dsrt_host_scene_build_bvh_gpu", "dsrt_host_scene_view", "dsrt_host_scene_bvh_stack_need", "dsrt_host_scene_texture_failures",
     "dsrt_scene_set_frame", "dsrt_read_pose_file", "dsrt_pose_to_frame", "dsrt_camera_look_at", "dsrt_decode_image_file", "dsrt_write_ppm", "dsrt_write_png",
@@ -177,6 +177,7 @@ def load():
     sig("dsrt_ctx_set_certified_tree", C.c_int, [vp, C.c_int])
     sig("dsrt_ctx_has_certified_tree", C.c_int, [vp])
     sig("dsrt_dropin_has_certified_tree", C.c_int, [])
+    sig("dsrt_host_scene_second_tree_probe", C.c_int, [vp, P(C.c_int), P(C.c_float), vp, vp, vp, C.c_int, vp, C.c_int])
     sig("dsrt_multi_create", C.c_int, [P(C.c_int), C.c_int, C.c_int, P(vp)])
     sig("dsrt_multi_destroy", None, [vp])
     sig("dsrt_multi_count", C.c_int, [vp])

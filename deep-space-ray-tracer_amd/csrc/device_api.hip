@@ -256,46 +256,15 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
             // bbox_hit's `t_max <= t_min` holds with equality, src/gpu_render.cu:312 -- are left OUT of the second tree; (b) every triangle's leaf box ON THE
             // REFERENCE TREE rides with its slot (tri_cert); (c) the second tree's boxes are widened by 2^-16 of the scene's extent, so that no rounding of the slab
             // arithmetic makes a ray miss the box of a triangle it hits (ray origins up to 30 extents away: render_impl checks the camera).
-            std::vector<uint8_t> unreachable((size_t)N, 0);
-            std::vector<float> leaf_box((size_t)N * 6, 0.0f);
-            {
-                struct Walk { int node; bool dead; };
-                std::vector<Walk> todo{{0, false}};
-                std::vector<char> seen((size_t)M, 0);
-                while (!todo.empty()) {
-                    Walk w = todo.back(); todo.pop_back();
-                    if (w.node < 0 || w.node >= M || seen[(size_t)w.node]) { set_error("BVH is not a tree"); return DSRT_ERR_INVALID; }
-                    seen[(size_t)w.node] = 1;
-                    const GPUBVHNode& n = h.bvh_nodes[w.node];
-                    const bool dead = w.dead || n.bbox_min.x == n.bbox_max.x || n.bbox_min.y == n.bbox_max.y || n.bbox_min.z == n.bbox_max.z;
-                    if (n.tri_count > 0) {
-                        if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
-                        for (int i = 0; i < n.tri_count; ++i) {
-                            const int t = h.tri_indices[n.tri_offset + i];
-                            if (t < 0 || t >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
-                            float* b = &leaf_box[6 * (size_t)t];
-                            b[0] = n.bbox_min.x; b[1] = n.bbox_min.y; b[2] = n.bbox_min.z; b[3] = n.bbox_max.x; b[4] = n.bbox_max.y; b[5] = n.bbox_max.z;
-                            if (dead) unreachable[(size_t)t] = 1;
-                        }
-                    } else { todo.push_back({n.left, dead}); todo.push_back({n.right, dead}); }
-                }
-            }
-            const GPUBVHNode& root = h.bvh_nodes[0];
-            const float extent = std::fmax(std::fmax(root.bbox_max.x - root.bbox_min.x, root.bbox_max.y - root.bbox_min.y), root.bbox_max.z - root.bbox_min.z);
-            std::vector<GPUBVHNode> nodes2;
-            std::vector<int> order2;
-            int height2 = 0;
-            int rc = build_sah_tree(h.triangles, (size_t)N, extent > 0.0f ? extent * (1.0f / 65536.0f) : 1.0e-6f, unreachable.data(), nodes2, order2, height2, second_tree_leaf_max());
+            SecondTree st2;
+            int rc = prepare_second_tree(h, second_tree_leaf_max(), st2);        // host/bvh_sah.cpp: unreachable triangles, reference-leaf boxes, the widened SAH tree, the checks
             if (rc != DSRT_OK) return rc;
-            // Rays also start on SPHERES (bounces, shadow rays): one whose surface reaches beyond 30 extents of the mesh puts origins where the widening above no longer
-            // covers the rounding of (box - origin) -- such a scene keeps the reference tree only.
-            bool origins_near = true;
-            for (int i = 0; i < h.num_spheres && origins_near; ++i) {
-                const GPUSphere& sp = h.spheres[i];
-                const double dx = (double)sp.center.x - 0.5 * ((double)root.bbox_min.x + root.bbox_max.x), dy = (double)sp.center.y - 0.5 * ((double)root.bbox_min.y + root.bbox_max.y),
-                             dz = (double)sp.center.z - 0.5 * ((double)root.bbox_min.z + root.bbox_max.z);
-                origins_near = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)sp.radius) <= 30.0 * (double)extent;
-            }
+            std::vector<GPUBVHNode>& nodes2 = st2.nodes;
+            std::vector<int>& order2 = st2.order;
+            std::vector<float>& leaf_box = st2.leaf_box;
+            const GPUBVHNode& root = h.bvh_nodes[0];
+            const float extent = st2.extent;
+            const bool origins_near = st2.origins_near;
             // (both trees share one array of node records addressed by a 32-bit byte offset: a scene too big for two trees in it keeps the reference tree only)
             const bool fits = nodes2.size() / 2 + (size_t)M / 2 + 2 * (size_t)kRefBias < ((size_t)1 << 26) && (order2.size() + (size_t)N) / 2 + nodes2.size() / 2 + (size_t)M / 2 < ((size_t)1 << 28);
             if (!nodes2.empty() && origins_near && fits) {

@@ -223,7 +223,74 @@ int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8
     return DSRT_OK;
 }
 
+int prepare_second_tree(const GPUScene& h, int leaf_max, SecondTree& out) {
+    const int N = h.num_triangles, M = h.num_bvh_nodes;
+    out = SecondTree{};
+    if (N <= 0 || M <= 0 || !h.bvh_nodes || !h.tri_indices || !h.triangles) return DSRT_OK;
+    out.unreachable.assign((size_t)N, 0);
+    out.leaf_box.assign((size_t)N * 6, 0.0f);
+    {
+        struct Walk { int node; bool dead; };
+        std::vector<Walk> todo{{0, false}};
+        std::vector<char> seen((size_t)M, 0);
+        while (!todo.empty()) {
+            Walk w = todo.back(); todo.pop_back();
+            if (w.node < 0 || w.node >= M || seen[(size_t)w.node]) { set_error("BVH is not a tree"); return DSRT_ERR_INVALID; }
+            seen[(size_t)w.node] = 1;
+            const GPUBVHNode& n = h.bvh_nodes[w.node];
+            const bool dead = w.dead || n.bbox_min.x == n.bbox_max.x || n.bbox_min.y == n.bbox_max.y || n.bbox_min.z == n.bbox_max.z;
+            if (n.tri_count > 0) {
+                if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
+                for (int i = 0; i < n.tri_count; ++i) {
+                    const int t = h.tri_indices[n.tri_offset + i];
+                    if (t < 0 || t >= N) { set_error("tri_indices entry out of range"); return DSRT_ERR_INVALID; }
+                    float* b = &out.leaf_box[6 * (size_t)t];
+                    b[0] = n.bbox_min.x; b[1] = n.bbox_min.y; b[2] = n.bbox_min.z; b[3] = n.bbox_max.x; b[4] = n.bbox_max.y; b[5] = n.bbox_max.z;
+                    if (dead) out.unreachable[(size_t)t] = 1;
+                }
+            } else { todo.push_back({n.left, dead}); todo.push_back({n.right, dead}); }
+        }
+    }
+    const GPUBVHNode& root = h.bvh_nodes[0];
+    out.extent = fmaxf(fmaxf(root.bbox_max.x - root.bbox_min.x, root.bbox_max.y - root.bbox_min.y), root.bbox_max.z - root.bbox_min.z);
+    out.pad = out.extent > 0.0f ? out.extent * (1.0f / 65536.0f) : 1.0e-6f;
+    const int rc = build_sah_tree(h.triangles, (size_t)N, out.pad, out.unreachable.data(), out.nodes, out.order, out.height, leaf_max);
+    if (rc != DSRT_OK) return rc;
+    // Rays also start on SPHERES (bounces, shadow rays): one whose surface reaches beyond 30 extents of the mesh puts origins where the widening no longer covers the
+    // rounding of (box - origin) -- such a scene keeps the reference tree only.
+    for (int i = 0; i < h.num_spheres && out.origins_near && h.spheres; ++i) {
+        const GPUSphere& sp = h.spheres[i];
+        const double dx = (double)sp.center.x - 0.5 * ((double)root.bbox_min.x + root.bbox_max.x), dy = (double)sp.center.y - 0.5 * ((double)root.bbox_min.y + root.bbox_max.y),
+                     dz = (double)sp.center.z - 0.5 * ((double)root.bbox_min.z + root.bbox_max.z);
+        out.origins_near = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)sp.radius) <= 30.0 * (double)out.extent;
+    }
+    return DSRT_OK;
+}
+
 }  // namespace dsrt
+
+// Test hook (no GPU): what dsrt_scene_upload would prepare for the certified second tree of this host scene.  counts = {triangles, unreachable on the reference tree,
+// triangles in the second tree, its nodes, its height, 1 if no sphere is too far}; arrays (any may be null): unreachable[triangles], leaf_box[6 * triangles], nodes, order.
+extern "C" int dsrt_host_scene_second_tree_probe(const DsrtHostScene* hs, int counts[6], float* pad, uint8_t* unreachable, float* leaf_box, GPUBVHNode* nodes, int max_nodes, int* order,
+                                                 int max_order) {
+    return dsrt::guarded("dsrt_host_scene_second_tree_probe", [&]() -> int {
+    if (!hs || !counts) { dsrt::set_error("dsrt_host_scene_second_tree_probe: null argument"); return DSRT_ERR_INVALID; }
+    GPUScene view;
+    int rc = dsrt_host_scene_view(hs, &view);
+    if (rc) return rc;
+    dsrt::SecondTree st;
+    if ((rc = dsrt::prepare_second_tree(view, 4, st))) return rc;
+    int dead = 0;
+    for (uint8_t u : st.unreachable) dead += u;
+    counts[0] = view.num_triangles; counts[1] = dead; counts[2] = (int)st.order.size(); counts[3] = (int)st.nodes.size(); counts[4] = st.height; counts[5] = st.origins_near ? 1 : 0;
+    if (pad) *pad = st.pad;
+    if (unreachable) std::copy(st.unreachable.begin(), st.unreachable.end(), unreachable);
+    if (leaf_box) std::copy(st.leaf_box.begin(), st.leaf_box.end(), leaf_box);
+    if (nodes) { if ((int)st.nodes.size() > max_nodes) { dsrt::set_error("node buffer too small"); return DSRT_ERR_INVALID; } std::copy(st.nodes.begin(), st.nodes.end(), nodes); }
+    if (order) { if ((int)st.order.size() > max_order) { dsrt::set_error("order buffer too small"); return DSRT_ERR_INVALID; } std::copy(st.order.begin(), st.order.end(), order); }
+    return DSRT_OK;
+    });
+}
 
 extern "C" int dsrt_host_scene_build_bvh_sah(DsrtHostScene* hs) {
     return dsrt::guarded("dsrt_host_scene_build_bvh_sah", [&]() -> int {

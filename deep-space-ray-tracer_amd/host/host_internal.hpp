@@ -48,6 +48,22 @@ inline unsigned builder_threads() {
 // bvh_sah.cpp: the binned-SAH builder on plain arrays (every triangle box widened by pad_all if > 0; triangles marked in `skip` left out)
 int build_sah_tree(const GPUTriangle* tris, size_t n, float pad_all, const uint8_t* skip, std::vector<GPUBVHNode>& nodes, std::vector<int>& order, int& height_out, int leaf_max);
 
+// The host half of the certified second tree (include/dsrt.h, dsrt_ctx_set_certified_tree; bvh_sah.cpp): from a scene with the reference's tree,
+//   unreachable[t]   1 = triangle t lies under a zero-thickness box of the reference tree: bbox_hit can never pass there (src/gpu_render.cu:312), the reference never reaches it
+//   leaf_box[6 t..]  lo, hi of the leaf of the reference tree that holds triangle t
+//   nodes, order     a binned-SAH tree over the REACHABLE triangles, every triangle box widened by pad = extent * 2^-16 (order = its tri_indices)
+//   origins_near     no sphere of the scene reaches beyond 30 extents of the mesh (rays also start on spheres)
+struct SecondTree {
+    std::vector<uint8_t> unreachable;
+    std::vector<float> leaf_box;
+    std::vector<GPUBVHNode> nodes;
+    std::vector<int> order;
+    int height = 0;
+    float extent = 0.0f, pad = 0.0f;
+    bool origins_near = true;
+};
+int prepare_second_tree(const GPUScene& h, int leaf_max, SecondTree& out);
+
 bool texture_flip_latch();
 void texture_flip_latch_set(bool v);
 

@@ -190,6 +190,11 @@ int  dsrt_ctx_device(const DsrtContext* ctx);
  * (about as much again as the scene) and the SAH build at upload (0.2 s per million triangles).  DSRT_TUNE_REFERENCE_WALK renders without it. */
 int  dsrt_ctx_set_certified_tree(DsrtContext* ctx, int on);
 int  dsrt_ctx_has_certified_tree(const DsrtContext* ctx);
+/* Test hook, no GPU involved: what the upload would prepare for the certified second tree of this host scene (which must carry the reference's tree).
+ * counts = {triangles, triangles the reference tree can never reach, triangles in the second tree, its nodes, its height, 1 if no sphere is too far away};
+ * *pad = the widening of its boxes; the arrays (each may be NULL) receive the per-triangle flags and reference-leaf boxes and the tree itself. */
+int  dsrt_host_scene_second_tree_probe(const DsrtHostScene* hs, int counts[6], float* pad, uint8_t* unreachable, float* leaf_box, GPUBVHNode* nodes, int max_nodes,
+                                       int* order, int max_order);
 int  dsrt_dropin_has_certified_tree(void);     /* the same question about the scene the drop-in gpu_render_scene converted last (it looks at DSRT_CERTIFIED_TREE on every call) */
 
 /* Upload + re-layout for the GPU (once per scene, not per frame).  `scene` holds HOST pointers in the
