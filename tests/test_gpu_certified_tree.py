@@ -238,3 +238,23 @@ def test_certified_tree_through_the_environment_reaches_the_drop_in_and_the_mult
         os.chdir(cwd)
         dsrt.lib.dsrt_free_gpu_scene(C.byref(dev))
     assert data == b"P6\n%d %d\n255\n" % (W, H) + want.tobytes()
+
+
+@pytest.mark.parametrize("scale", [1.0e-15, 1.0 / 64.0, 4096.0, 1.0e9])
+def test_scaled_scenes_on_the_certified_tree_match_the_oracle_and_pass_the_audit(dsrt, cert_ctx, oracle, scale):
+    """The widening of the second tree's boxes and the relaxation of its distance culling are RELATIVE (2^-16 of the scene's extent, 2^-10 of t): the station from 1e-15 to
+    1e9 times its size, camera moved with it -- image bits equal the oracle's, and the audit finds no answer of the second tree that differs from the reference walk's."""
+    from conftest import ASSETS
+    hs = dsrt.HostScene().add_obj(os.path.join(ASSETS, "station_3k.obj"), scale=scale)
+    hs.build_bvh()
+    W, H, spp, depth = 160, 90, 8, 50
+    cam = dsrt.camera_look_at(tuple(c * scale for c in (12.0, 9.0, 38.0)), (0.0, 0.0, 0.0), 40.0, W, H, spp, depth)
+    scene = hs.view(cam, SUN)
+    want_rgb, want_f32, _ = oracle.render(scene, W, H)
+    cert_ctx.upload(scene)
+    assert cert_ctx.has_certified_tree
+    rgb, f32, st = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth), want_f32=True)
+    assert st.certified_tree_used == 1
+    assert np.array_equal(rgb, want_rgb) and np.array_equal(f32.view(np.uint32), want_f32.view(np.uint32))
+    rgb, _, st = cert_ctx.render_to_host(dsrt.make_desc(W, H, spp, depth, collect_counters=3))
+    assert np.array_equal(rgb, want_rgb) and st.certificate_audit_mismatches == 0 and st.certificate_audited > 0
