@@ -238,7 +238,10 @@ int prepare_second_tree(const GPUScene& h, int leaf_max, SecondTree& out) {
             if (w.node < 0 || w.node >= M || seen[(size_t)w.node]) { set_error("BVH is not a tree"); return DSRT_ERR_INVALID; }
             seen[(size_t)w.node] = 1;
             const GPUBVHNode& n = h.bvh_nodes[w.node];
-            const bool dead = w.dead || n.bbox_min.x == n.bbox_max.x || n.bbox_min.y == n.bbox_max.y || n.bbox_min.z == n.bbox_max.z;
+            // (a box with a NaN bound passes bbox_hit's comparisons on that axis whatever the ray: no statement about reachability is safe -- such a tree gets no second tree)
+            if (std::isnan(n.bbox_min.x + n.bbox_min.y + n.bbox_min.z + n.bbox_max.x + n.bbox_max.y + n.bbox_max.z)) { out = SecondTree{}; out.origins_near = false; return DSRT_OK; }
+            // zero thickness -- or an inverted box, which fails the same comparison -- on any axis: `t_max <= t_min` (:312) holds for every ray
+            const bool dead = w.dead || !(n.bbox_min.x < n.bbox_max.x) || !(n.bbox_min.y < n.bbox_max.y) || !(n.bbox_min.z < n.bbox_max.z);
             if (n.tri_count > 0) {
                 if (n.tri_offset < 0 || (long long)n.tri_offset + n.tri_count > N) { set_error("BVH leaf range out of bounds"); return DSRT_ERR_INVALID; }
                 for (int i = 0; i < n.tri_count; ++i) {
