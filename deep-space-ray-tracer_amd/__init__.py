@@ -213,11 +213,12 @@ def set_experiment(word):
     _check(lib.dsrt_dev_set_experiment(int(word) & 0xFFFFFFFF), "dsrt_dev_set_experiment")
 
 
-def microbench_copy(nbytes=2 << 30, blocks_per_cu=8, reps=8, device=0):
-    """HBM streaming-copy calibration (include/dsrt.h): float4 grid-stride copy; GB/s counts bytes read + written."""
+def microbench_copy(nbytes=2 << 30, blocks_per_cu=8, reps=8, device=0, mode=0):
+    """HBM streaming calibration (include/dsrt.h): float4 grid-stride kernel; mode 0 copy (GB/s counts bytes read + written), 1 read only, 2 write only, 3 non-temporal copy."""
     ms, moved = C.c_float(), C.c_double()
-    _check(lib.dsrt_microbench_copy(int(device), int(nbytes), int(blocks_per_cu), int(reps), C.byref(ms), C.byref(moved)), "dsrt_microbench_copy")
-    return {"bytes_per_buffer": int(nbytes), "blocks_per_cu": blocks_per_cu, "reps": reps, "ms": ms.value, "GBps": moved.value / ms.value / 1e6}
+    _check(lib.dsrt_microbench_copy(int(device), int(mode), int(nbytes), int(blocks_per_cu), int(reps), C.byref(ms), C.byref(moved)), "dsrt_microbench_copy")
+    return {"mode": ("copy", "read only", "write only", "non-temporal copy")[mode], "bytes_per_buffer": int(nbytes), "blocks_per_cu": blocks_per_cu, "reps": reps, "ms": ms.value,
+            "GBps": moved.value / ms.value / 1e6}
 
 
 def microbench_gather(mode=0, dependent=False, live_lanes=64, pad_valu=0, table_bytes=19 << 20, iters=2000, device=0):

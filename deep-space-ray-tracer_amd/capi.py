@@ -149,7 +149,7 @@ def load():
     sig("dsrt_sizeof", C.c_size_t, [C.c_int])
     sig("dsrt_dev_set_experiment", C.c_int, [C.c_uint32])
     sig("dsrt_selftest_poke_node_word", C.c_int, [vp, C.c_size_t, C.c_uint32, P(C.c_uint32)])
-    sig("dsrt_microbench_copy", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, P(C.c_float), P(C.c_double)])
+    sig("dsrt_microbench_copy", C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, P(C.c_float), P(C.c_double)])
     sig("dsrt_host_scene_create", vp, [])
     sig("dsrt_host_scene_destroy", None, [vp])
     sig("dsrt_host_scene_add_obj", C.c_int, [vp, C.c_char_p, C.c_double])

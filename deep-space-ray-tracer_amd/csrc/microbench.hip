@@ -444,18 +444,31 @@ extern "C" int dsrt_microbench_gather(int device, int mode, int dependent, int l
 
 // Streaming-copy calibration: what this board's HBM delivers to a plain float4 grid-stride copy (16 B per lane per access, read + write counted), the
 // denominator next to the spec's 8 TB/s.  Buffers far beyond the 256 MB Infinity Cache, so that neither side is served on the die.
+typedef float nt_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load(const float4* p) { const nt_v4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void nt_store(float4 a, float4* p) { nt_v4 v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<nt_v4*>(p)); }
+
+// MODE 0: copy; 1: read only (every lane sums what it loads, one store per lane at the end); 2: write only; 3: copy with non-temporal loads and stores
+template <int MODE>
 __global__ void __launch_bounds__(256) dsrt_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {               // four independent 16-byte loads in flight per lane, then the four stores
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const size_t first = i;
+    for (; i + 3 * stride < n; i += 4 * stride) {               // four independent 16-byte accesses in flight per lane
+        float4 a = acc, b = acc, c = acc, d = acc;
+        if (MODE == 3) { a = nt_load(src + i); b = nt_load(src + i + stride); c = nt_load(src + i + 2 * stride); d = nt_load(src + i + 3 * stride); }
+        else if (MODE != 2) { a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride]; }
+        if (MODE == 1) { acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y; acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w; }
+        else if (MODE == 3) { nt_store(a, dst + i); nt_store(b, dst + i + stride); nt_store(c, dst + i + 2 * stride); nt_store(d, dst + i + 3 * stride); }
+        else { dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d; }
     }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (; i < n; i += stride) { if (MODE == 1) acc.x += src[i].x; else if (MODE == 2) dst[i] = acc; else dst[i] = src[i]; }
+    if (MODE == 1) dst[first] = acc;
 }
 
-extern "C" int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved) {
-    if (bytes < ((size_t)1 << 20) || bytes > ((size_t)1 << 36) || blocks_per_cu < 1 || blocks_per_cu > 64 || reps < 1 || reps > 1000 || !out_ms || !out_bytes_moved) {
+extern "C" int dsrt_microbench_copy(int device, int mode, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved) {
+    if (mode < 0 || mode > 3 || bytes < ((size_t)1 << 20) || bytes > ((size_t)1 << 36) || blocks_per_cu < 1 || blocks_per_cu > 64 || reps < 1 || reps > 1000 || !out_ms || !out_bytes_moved) {
         dsrt::set_error("dsrt_microbench_copy: bad argument");
         return DSRT_ERR_INVALID;
     }
@@ -478,16 +491,22 @@ extern "C" int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu,
     MB_TRY(hipEventCreate(&e0));
     MB_TRY(hipEventCreate(&e1));
     const int blocks = prop.multiProcessorCount * blocks_per_cu;
-    hipLaunchKernelGGL(dsrt_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);       // warm-up
+    auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(dsrt_copy_kernel<0>, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+        else if (mode == 1) hipLaunchKernelGGL(dsrt_copy_kernel<1>, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+        else if (mode == 2) hipLaunchKernelGGL(dsrt_copy_kernel<2>, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+        else hipLaunchKernelGGL(dsrt_copy_kernel<3>, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+    };
+    launch();                                                                                                         // warm-up
     MB_TRY(hipGetLastError());
     MB_TRY(hipDeviceSynchronize());
     MB_TRY(hipEventRecord(e0, nullptr));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(dsrt_copy_kernel, dim3(blocks), dim3(256), 0, nullptr, (const float4*)src, dst, n);
+    for (int r = 0; r < reps; ++r) launch();
     MB_TRY(hipGetLastError());
     MB_TRY(hipEventRecord(e1, nullptr));
     MB_TRY(hipEventSynchronize(e1));
     MB_TRY(hipEventElapsedTime(out_ms, e0, e1));
-    *out_bytes_moved = 2.0 * (double)(n * sizeof(float4)) * (double)reps;
+    *out_bytes_moved = (mode == 1 || mode == 2 ? 1.0 : 2.0) * (double)(n * sizeof(float4)) * (double)reps;
     cleanup();
     return DSRT_OK;
 }

@@ -422,10 +422,11 @@ int dsrt_microbench_valu_kinds(void);
 const char* dsrt_microbench_valu_kind_name(int kind);
 
 /* The third calibration: what this board's HBM delivers to a plain streaming copy -- a float4 grid-stride kernel (16 bytes per lane per access), `blocks_per_cu`
- * 256-thread workgroups per CU, `bytes` per buffer (take it far beyond the 256 MB Infinity Cache), `reps` launches back to back.  Returns the time (HIP events)
+ * 256-thread workgroups per CU, `bytes` per buffer (take it far beyond the 256 MB Infinity Cache), `reps` launches back to back; `mode` 0 = copy, 1 = read only,
+ * 2 = write only, 3 = copy with non-temporal loads and stores.  Returns the time (HIP events)
  * and the bytes moved (read + written).  The figure bench.py prints as extras.hbm_copy_GBps_measured, next to the 8 TB/s of the specification.
  * No reference interface: measurement only. */
-int dsrt_microbench_copy(int device, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved);
+int dsrt_microbench_copy(int device, int mode, size_t bytes, int blocks_per_cu, int reps, float* out_ms, double* out_bytes_moved);
 
 /* ===================================================================================== */
 /* Drop-in layer: the reference's own three entry points.                                */
