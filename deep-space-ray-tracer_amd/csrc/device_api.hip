@@ -457,7 +457,7 @@ bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
 //   bit 31       rng_mode 1: background pixels one item each
 // Apart from bit 27 none of them changes a pixel (tests/test_gpu_parity.py runs the render under several of them against the oracle).
 constexpr uint32_t kExperimentDefined = 64u | 128u | (0xFFFu << 8) | (7u << 20) | (1u << 24) | (3u << 25) | (1u << 27) | (3u << 28) | (1u << 30) | (1u << 31);
-constexpr int kCoopDefault = 0;             // walking lanes at or below which a wave walks its fresh rays cooperatively (0 = never)
+constexpr int kCoopDefault = 16;            // walking lanes at or below which a wave of a rank's share walks its fresh rays cooperatively
 std::atomic<uint32_t> g_experiment{0u};
 
 int set_experiment(uint32_t word, const char* from) {
@@ -749,10 +749,13 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         else ok = near_enough(ctx->camera.origin);
         a.accel = ok ? 1 : 0;
     }
+    // The cooperative walk (render_kernel.hip: coop_walk): rng_mode 0, single-frame launches whose rays walk the second tree.  By default only a rank's SHARE of a frame
+    // uses it (and with it the kernels' COOP instantiation): there the chip is never full and the longest chains bound the launch.
     a.coop = 0;
-    if (a.accel && sc.view.wide) {
-        static const int kCoopOfCode[8] = {kCoopDefault, 0, 4, 8, 16, 24, 32, 64};
-        a.coop = kCoopOfCode[((xp >> 25) & 3u) | ((xp >> 28) & 4u)];
+    if (a.accel && sc.view.wide && desc->rng_mode == 0 && !batch) {
+        static const int kCoopOfCode[8] = {-1, 0, 4, 8, 16, 24, 32, 64};
+        const int code = kCoopOfCode[((xp >> 25) & 3u) | ((xp >> 28) & 4u)];
+        a.coop = code >= 0 ? code : (desc->shard_count > 1 ? kCoopDefault : 0);
     }
     a.audit = a.accel && desc->collect_counters == 3 ? 1 : 0;
     // Walks of the second tree are a third shorter, so an advance pass is dearer against a node iteration than on the reference tree: the traverse phase stays three times
