@@ -89,7 +89,7 @@ class DsrtStats(C.Structure):
                [(n, C.c_uint64) for n in ("samples", "rays", "primary_hits", "box_fetches", "nodes_entered", "internal_entered", "tri_tests",
                                           "hit_updates", "sphere_tests", "shaded_hits", "tex_fetches", "stack_spills", "max_stack",
                                           "node_slots", "tri_slots", "adv_slots", "adv_active", "idle_at_leaf", "idle_waiting", "idle_done", "visits_depth_lt6", "visits_depth_lt9", "visits_depth_lt12", "tiles_total", "tiles_culled", "wave_ticks", "certificate_fallbacks", "certificate_audited", "certificate_audit_mismatches")] + \
-               [(n, C.c_float) for n in ("heavy_queue_empty_ms", "light_queue_empty_ms", "last_wave_exit_ms")] + [("certified_tree_used", C.c_int)] + [(n, C.c_uint64) for n in ("coop_rays", "coop_visits", "coop_overflows")]
+               [(n, C.c_float) for n in ("heavy_queue_empty_ms", "light_queue_empty_ms", "last_wave_exit_ms")] + [("certified_tree_used", C.c_int)]
 
 
 # numpy record layouts of the reference arrays (for dumping / comparing with goldens)
@@ -103,7 +103,7 @@ assert TRI_DTYPE.itemsize == 116 and NODE_DTYPE.itemsize == 40 and MAT_DTYPE.ite
 
 # The ABI version THESE hand-written structs were laid out for (include/dsrt.h, DSRT_ABI_VERSION).  load() requires library == header == this, and compares the sizes
 # of the structs above with the library's own (dsrt_sizeof): a header and library bumped without this file are refused, not mis-laid.
-ABI_VERSION = 8
+ABI_VERSION = 7
 
 EXPORTS = [
     "dsrt_last_error", "dsrt_abi_version", "dsrt_sizeof", "dsrt_microbench_copy", "dsrt_dev_set_experiment", "dsrt_selftest_poke_node_word", "dsrt_ctx_set_certified_tree", "dsrt_ctx_has_certified_tree", "dsrt_dropin_has_certified_tree", "dsrt_host_scene_second_tree_probe",

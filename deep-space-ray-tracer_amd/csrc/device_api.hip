@@ -13,7 +13,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -96,7 +95,7 @@ struct DevBuf {
 
 // The scene in traversal layout, owning its device memory.
 struct PackedScene {
-    DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, tri_cert, materials, wide;
+    DevBuf<float4> pairs, tri_pairs, tri_shade, tri_uv, tri_cert, materials;
     DevBuf<uint8_t> pair_depth;
     DevBuf<int2> big_leaves;
     DevBuf<GPUSphere> spheres;
@@ -225,53 +224,6 @@ int pack_tree(const GPUScene& h, const GPUBVHNode* nodes, int M, const int* tri_
     return DSRT_OK;
 }
 
-// THE WIDE FORM OF THE SECOND TREE (render_kernel.hip: coop_walk).  The second tree's packed records, collapsed top-down into nodes of up to kWideChildren children: a node
-// starts as the two children of a binary record and the internal child of largest surface area is replaced by its own two children until the node is full or
-// only leaves are left.  Child j of node i is two float4 at wide[(i * kWideChildren + j) * 2]: (lo.x, lo.y, lo.z, hi.x) (hi.y, hi.z, ref, -); ref >= 0 is a wide node,
-// ref < 0 a leaf reference as the binary records hold it (the same pair records), an unused slot is an inverted box with ref kWideEmpty.  Nodes are laid out
-// breadth first (node 0 = the root's expansion).  Boxes are the binary records' own (already widened), so a walk of this form is as conservative as a walk of the
-// binary form; what it returns is judged by the same certificate.
-void build_wide_tree(const std::vector<float4>& pairs, int root_ref, std::vector<float4>& wide) {
-    wide.clear();
-    if (!ref_is_internal(root_ref)) return;
-    struct Child { float lo[3], hi[3]; int ref; };
-    auto children_of = [&](int ref, Child out[2]) {
-        const float4* r = pairs.data() + 4 * (size_t)(ref - kRefBias);
-        out[0] = Child{{r[0].x, r[1].x, r[2].x}, {r[0].z, r[1].z, r[2].z}, 0};
-        out[1] = Child{{r[0].y, r[1].y, r[2].y}, {r[0].w, r[1].w, r[2].w}, 0};
-        std::memcpy(&out[0].ref, &r[3].x, 4);
-        std::memcpy(&out[1].ref, &r[3].y, 4);
-    };
-    auto area = [](const Child& c) { const double x = (double)c.hi[0] - c.lo[0], y = (double)c.hi[1] - c.lo[1], z = (double)c.hi[2] - c.lo[2]; return x * y + y * z + z * x; };
-    std::vector<int> queue{root_ref};                                   // binary reference of every wide node, in layout order
-    for (size_t i = 0; i < queue.size(); ++i) {
-        Child ch[kWideChildren];
-        int n = 2;
-        children_of(queue[i], ch);
-        while (n < kWideChildren) {
-            int best = -1;
-            for (int k = 0; k < n; ++k) if (ref_is_internal(ch[k].ref) && (best < 0 || area(ch[k]) > area(ch[best]))) best = k;
-            if (best < 0) break;
-            Child two[2];
-            children_of(ch[best].ref, two);
-            ch[best] = two[0];
-            ch[n++] = two[1];
-        }
-        wide.resize((i + 1) * kWideChildren * 2);
-        for (int k = 0; k < kWideChildren; ++k) {
-            float4* w = wide.data() + (i * kWideChildren + k) * 2;
-            if (k >= n) {
-                const float inf = std::numeric_limits<float>::infinity();
-                w[0] = as_f4(inf, inf, inf, -inf); w[1] = as_f4(-inf, -inf, bits(kWideEmpty), 0.0f);
-                continue;
-            }
-            int ref = ch[k].ref;
-            if (ref_is_internal(ref)) { queue.push_back(ref); ref = (int)queue.size() - 1; }
-            w[0] = as_f4(ch[k].lo[0], ch[k].lo[1], ch[k].lo[2], ch[k].hi[0]); w[1] = as_f4(ch[k].hi[1], ch[k].hi[2], bits(ref), 0.0f);
-        }
-    }
-}
-
 // Host-side conversion of reference-layout arrays into the traversal layout.  `second_tree`: also build and pack the certified second tree (below).
 int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
     const int N = h.num_triangles, M = h.num_bvh_nodes;
@@ -285,7 +237,7 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
     for (int i = 0; i < h.num_spheres; ++i) if (h.spheres[i].material_id < 0 || h.spheres[i].material_id >= h.num_materials) { set_error("sphere material id out of range"); return DSRT_ERR_INVALID; }
 
     PackArrays arr;
-    std::vector<float4> mats, wide;
+    std::vector<float4> mats;
     DeviceScene& v = out.view;
     std::memset(&v, 0, sizeof v);
     v.root_ref = kRefNone;
@@ -318,7 +270,6 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
             if (!nodes2.empty() && origins_near && fits) {
                 if ((rc = pack_tree(h, nodes2.data(), (int)nodes2.size(), order2.data(), (int)order2.size(), textured, leaf_box.data(), arr, acc_tree))) return rc;
                 out.has_second_tree = true;
-                build_wide_tree(arr.pairs, acc_tree.root_ref, wide);          // (the second tree is packed first: its records are the only ones in arr.pairs here)
                 out.scene_extent = extent;
                 for (int a = 0; a < 3; ++a) out.scene_centre[a] = 0.5f * ((&root.bbox_min.x)[a] + (&root.bbox_max.x)[a]);
             }
@@ -361,7 +312,7 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
         if ((rc = out.pair_depth.upload(depth_bytes))) return rc;
     }
     if ((rc = out.pairs.upload(pairs)) || (rc = out.tri_pairs.upload(isect)) || (rc = out.tri_shade.upload(shade)) ||
-        (rc = out.tri_uv.upload(uv)) || (rc = out.tri_cert.upload(arr.cert)) || (rc = out.wide.upload(wide)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
+        (rc = out.tri_uv.upload(uv)) || (rc = out.tri_cert.upload(arr.cert)) || (rc = out.big_leaves.upload(big)) || (rc = out.materials.upload(mats))) return rc;
     std::vector<GPUSphere> sph(h.spheres, h.spheres + h.num_spheres);
     if ((rc = out.spheres.upload(sph))) return rc;
     if (h.num_textures > 0 && h.textures && h.texture_pool) {
@@ -370,7 +321,7 @@ int pack_scene(const GPUScene& h, PackedScene& out, bool second_tree) {
         if ((rc = out.tex_headers.upload(th)) || (rc = out.tex_pool.upload(pool))) return rc;
     } else { out.tex_headers.reset(); out.tex_pool.reset(); }
 
-    v.pair_depth = out.pair_depth.p; v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p; v.tri_cert = out.tri_cert.p; v.wide = out.wide.p; v.num_wide = (int)(wide.size() / (kWideChildren * 2));
+    v.pair_depth = out.pair_depth.p; v.pairs = out.pairs.p; v.pairs_biased = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(out.pairs.p) - (uintptr_t)kRefBias * 64u); v.tri_pairs = out.tri_pairs.p; v.tri_shade = out.tri_shade.p; v.tri_uv = out.tri_uv.p; v.tri_cert = out.tri_cert.p;
     v.big_leaves = out.big_leaves.p; v.materials = out.materials.p; v.spheres = out.spheres.p;
     v.tex_headers = out.tex_headers.p; v.tex_pool = out.tex_pool.p;
     v.num_pairs = (int)(pairs.size() / 4); v.num_tri_pairs = (int)(isect.size() / 5); v.num_big_leaves = (int)big.size();
@@ -450,14 +401,12 @@ bool make_tiling(const DsrtRenderDesc& d, Tiling& t) {
 //   bits 8-19    rng_mode 1: slices per heavy pixel (0 = chosen by the pre-pass)
 //   bits 20-22   grid = resident set >> n (frames that overlap on separate streams)
 //   bit 24       the general kernels even for a scene that qualifies for the LEAN instantiation (A/B of the two)
-//   bits 25-26, 30  cooperative walk threshold (render_kernel.hip: coop_walk): code 0 = the default, 1 = off, 2..7 = 4, 8, 16, 24, 32, 64 walking lanes
 //   bit 27       COUNTING BUILD of rng_mode 0 only: the float image receives per pixel (fetch time, end time, wave) as bit patterns,
 //                100 MHz ticks, instead of the colour (tools/chain_timeline.py) -- the one switch that changes output (the float image; never the bytes)
 //   bits 28-29   rng_mode 1: least samples per work item of a background pixel, 0 = 128, 1 = 64, 2 = 256, 3 = 512
 //   bit 31       rng_mode 1: background pixels one item each
 // Apart from bit 27 none of them changes a pixel (tests/test_gpu_parity.py runs the render under several of them against the oracle).
-constexpr uint32_t kExperimentDefined = 64u | 128u | (0xFFFu << 8) | (7u << 20) | (1u << 24) | (3u << 25) | (1u << 27) | (3u << 28) | (1u << 30) | (1u << 31);
-constexpr int kCoopDefault = 16;            // walking lanes at or below which a wave of a rank's share walks its fresh rays cooperatively
+constexpr uint32_t kExperimentDefined = 64u | 128u | (0xFFFu << 8) | (7u << 20) | (1u << 24) | (1u << 27) | (3u << 28) | (1u << 31);
 std::atomic<uint32_t> g_experiment{0u};
 
 int set_experiment(uint32_t word, const char* from) {
@@ -749,14 +698,6 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         else ok = near_enough(ctx->camera.origin);
         a.accel = ok ? 1 : 0;
     }
-    // The cooperative walk (render_kernel.hip: coop_walk): rng_mode 0, single-frame launches whose rays walk the second tree.  By default only a rank's SHARE of a frame
-    // uses it (and with it the kernels' COOP instantiation): there the chip is never full and the longest chains bound the launch.
-    a.coop = 0;
-    if (a.accel && sc.view.wide && desc->rng_mode == 0 && !batch) {
-        static const int kCoopOfCode[8] = {-1, 0, 4, 8, 16, 24, 32, 64};
-        const int code = kCoopOfCode[((xp >> 25) & 3u) | ((xp >> 28) & 4u)];
-        a.coop = code >= 0 ? code : (desc->shard_count > 1 ? kCoopDefault : 0);
-    }
     a.audit = a.accel && desc->collect_counters == 3 ? 1 : 0;
     // Walks of the second tree are a third shorter, so an advance pass is dearer against a node iteration than on the reference tree: the traverse phase stays three times
     // longer before it yields (interleaved medians, near frame: 760 -> 741 ms in rng_mode 0, 734 -> 701 in rng_mode 1; the reference walk gains nothing from it).
@@ -901,7 +842,6 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
         stats->certificate_fallbacks = cnt[C_CERT_FALLBACKS];
         stats->certificate_audited = cnt[C_AUDITED]; stats->certificate_audit_mismatches = cnt[C_AUDIT_MISMATCHES];
         stats->certified_tree_used = a.accel;
-        stats->coop_rays = cnt[C_COOP_RAYS]; stats->coop_visits = cnt[C_COOP_VISITS]; stats->coop_overflows = cnt[C_COOP_OVERFLOWS];
         {   // time marks relative to the first wave's start, in ms (0 when the mark was never passed)
             const double t0 = (double)~cnt[C_T_FIRST];
             stats->heavy_queue_empty_ms = cnt[C_T_HEAVY_EMPTY] ? (float)(((double)~cnt[C_T_HEAVY_EMPTY] - t0) * 1e-5) : 0.0f;

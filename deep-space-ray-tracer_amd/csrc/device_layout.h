@@ -48,8 +48,6 @@ constexpr int kLeafBit = (int)0x80000000u;
 constexpr int kRefNone = 62;
 constexpr int kRefPop = 63;
 constexpr int kRefBias = 64;
-constexpr int kWideChildren = 8;           // children of a node of the second tree's wide form = lanes that walk one ray together (render_kernel.hip: coop_walk)
-constexpr int kWideEmpty = 0x7FFFFFFF;
 
 __host__ __device__ inline bool ref_is_leaf(int r) { return r < 0; }
 __host__ __device__ inline bool ref_is_internal(int r) { return r >= kRefBias; }
@@ -81,10 +79,6 @@ struct DeviceScene {
     int   accel_root_ref;      // the second tree's root (kRefNone: none)
     float accel_root_lo[3];
     float accel_root_hi[3];
-    // The second tree in wide form (device_api.hip: build_wide_tree; render_kernel.hip: coop_walk): kWideChildren children per node, two float4 per child
-    // (lo.xyz, hi.x) (hi.yz, ref, -); ref >= 0 a wide node, < 0 a leaf reference, kWideEmpty an unused slot.  Null when there is no second tree (or its root is a leaf).
-    const float4* wide;
-    int   num_wide;
 };
 
 constexpr int kCamOrigin = 0, kCamLlc = 3, kCamHorizontal = 6, kCamVertical = 9;     // offsets into FrameParams::cam / BatchFrame::cam
@@ -156,7 +150,6 @@ struct RenderArgs {
     int       leaf_ratio4;     // x10: the node loop yields to the leaf pass once (parked lane-slots wasted) >= this/10 * descending lanes
     int       deal_leaves;     // 1: a parked leaf's second pair record is evaluated by a lane that is not at a leaf (render_kernel.hip, phase L)
     int       accel;           // 1: rays start on the certified second tree and fall back to the reference tree when the certificate fails (path_machine.h)
-    int       coop;            // > 0: a wave with at most this many rays to walk walks the fresh ones on the wide form of the second tree, kWideChildren lanes per ray (render_kernel.hip: coop_walk)
     int       audit;           // counting build: 1 = every answer of the second tree is also walked on the reference tree and compared (path_machine.h, CERTIFICATE AUDIT)
 };
 
@@ -164,7 +157,7 @@ struct RenderArgs {
 enum Counter { C_SAMPLES, C_RAYS, C_PRIMARY_HITS, C_BOX_FETCHES, C_NODES_ENTERED, C_INTERNAL_ENTERED, C_TRI_TESTS, C_HIT_UPDATES,
                C_SPHERE_TESTS, C_SHADED_HITS, C_TEX_FETCHES, C_STACK_SPILLS, C_MAX_STACK,
                C_NODE_SLOTS, C_TRI_SLOTS, C_ADV_SLOTS, C_ADV_ACTIVE,
-               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_CERT_FALLBACKS, C_AUDITED, C_AUDIT_MISMATCHES, C_WAVE_TICKS, C_COOP_RAYS, C_COOP_VISITS, C_COOP_OVERFLOWS,
+               C_IDLE_AT_LEAF, C_IDLE_WAITING, C_IDLE_DONE, C_VISITS_LT6, C_VISITS_LT9, C_VISITS_LT12, C_CERT_FALLBACKS, C_AUDITED, C_AUDIT_MISMATCHES, C_WAVE_TICKS,
                C_T_FIRST, C_T_HEAVY_EMPTY, C_T_LIGHT_EMPTY, C_T_LAST,      // wall-clock marks (100 MHz ticks), kept as maxima: the first three of ~t
                kNumCounters };
 

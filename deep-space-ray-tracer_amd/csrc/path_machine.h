@@ -39,7 +39,7 @@ constexpr uint32_t kAwait = 1u << 8;
 // The certified second tree (args.accel; device_api.hip: pack_scene).  A ray starts on the second tree with its distance culling relaxed by kCullRelax; when its walk
 // ends, the CERTIFICATE decides whether the answer is provably the reference walk's (advance_step), and if not the same ray walks the reference tree.
 //              bit 10 kOnRef: this ray is (re-)walking the reference tree: its answer is final;  bit 11 kTie: the last accept on the second tree was an equality accept
-constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11, kAudit = 1u << 12, kNoCoop = 1u << 13;   // (kAudit: counting build, RenderArgs::audit -- this ray's certified answer is being checked against the reference walk)
+constexpr uint32_t kOnRef = 1u << 10, kTie = 1u << 11, kAudit = 1u << 12;   // (kAudit: counting build, RenderArgs::audit -- this ray's certified answer is being checked against the reference walk)
 #ifndef DSRT_CULL_RELAX_DIV
 #define DSRT_CULL_RELAX_DIV 1024.0f
 #endif
@@ -679,7 +679,7 @@ __device__ __forceinline__ void advance_step(Lane& ln, const RenderArgs& args, u
         const bool second = args.accel != 0;
         ln.cull = kTMax;
         ln.relax = second ? kCullRelax : 1.0f;
-        ln.aux &= ~(kOnRef | kTie | kNoCoop);
+        ln.aux &= ~(kOnRef | kTie);
         const int root_ref = second ? S.accel_root_ref : S.root_ref;
         if (root_ref != kRefNone) {
             if (COUNT) c[C_BOX_FETCHES]++;

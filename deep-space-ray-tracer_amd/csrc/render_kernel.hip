@@ -89,179 +89,10 @@ __device__ __forceinline__ bool apply_pair(Lane& ln, uint32_t* c, int slot_a, v2
     return stop;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// COOPERATIVE WALK: one ray, kWideChildren lanes.
-// A wave at the end of a launch (or a rank's share of a frame on N GPUs) holds a few pixels that are 1000-sample serial chains (rng_mode 0) and lanes with nothing to
-// do; what bounds the launch is then the LATENCY of one ray's walk -- ~50 dependent node visits of ~0.65 us each for a wave alone on its SIMD (tools/chain_probe.py).
-// The second tree is free in shape and in who walks it (its answers are certified one by one, path_machine.h), so such a wave walks each FRESH ray with a group of
-// eight lanes on the tree's wide form (device_api.hip: build_wide_tree): lane j of the group tests child j's box, the group descends into the nearest hit child and
-// postpones the others on a stack of its own in LDS, lanes whose child is a leaf intersect its triangles at once, and accepted triangles are merged into the group's
-// `closest` in lane order with apply_pair's own rules (accept iff !(t > closest); an equality accept over an earlier hit is a tie).  Eight rays at a time, one per
-// group; a group that finishes takes the wave's next fresh ray.  The owner lane gets (closest, slot, u, v, tie) back exactly as if it had walked the binary form itself, and its certificate (advance_step) judges it.
-// A group whose stack overflows gives its ray back untouched (kNoCoop: it walks the binary form).
-#ifndef DSRT_COOP_STACK
-#define DSRT_COOP_STACK 24
-#endif
-constexpr int kCoopStack = DSRT_COOP_STACK;          // postponed children per group (a group whose stack is full gives its ray back)
-__device__ __forceinline__ float bperm_f(int addr4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(v))); }
-__device__ __forceinline__ float group8_min(float v) {          // minimum over the eight lanes of a group, in every lane of it (two quad permutes and the half-row mirror)
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
-    return v;
-}
-
-// n-th set bit (n = 0: the lowest) of a mask, or -1
-__device__ __forceinline__ int nth_bit64(unsigned long long m, int n) {
-#pragma unroll
-    for (int k = 0; k < kWideChildren - 1; ++k) if (k < n) m &= m - 1ull;
-    return m ? __builtin_ctzll(m) : -1;
-}
-
-template <bool COUNT, bool CHECKED, bool ANYHIT>
-__device__ __forceinline__ void coop_walk(Lane& ln, const DeviceScene& S, uint32_t* c, uint32_t& flags, uint2* stack_of_wave, unsigned long long todo, const int lane) {
-    const int j = lane & (kWideChildren - 1), base = lane & ~(kWideChildren - 1), g = lane >> 3;
-    uint2* const stk = stack_of_wave + g * kCoopStack;
-    // The groups are persistent: a group that has finished its ray takes the next one of `todo` at once, so the walk of many rays costs their AVERAGE length per group,
-    // not the longest of every eight.  Group state is held identically by the group's eight lanes; `my_group` is the owner's side: which group walks THIS lane's ray.
-    F3 gro = mk(0, 0, 0), grd = gro, grinv = gro;
-    bool shadow = false, busy = false;
-    float gclosest = kTMax, gcull = kTMax, gu = 0.0f, gv = 0.0f;
-    int ghit = -1, gtie = 0, gfail = 0, node = -1, gsp = 0, my_group = -1;
-    uint32_t guard = 0;
-    for (;;) {
-        const unsigned long long busy_m = wave_ballot(busy);
-        if (todo != 0ull && ~busy_m != 0ull) {
-            // hand the next rays of `todo` (lowest lane first) to the idle groups (lowest group first)
-            uint32_t idle8 = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) idle8 |= (uint32_t)((~busy_m >> (8 * k)) & 1ull) << k;
-            const int n_idle = __popc(idle8), n_todo = __popcll(todo);
-            const int n = n_idle < n_todo ? n_idle : n_todo;
-            const int owner = busy ? -1 : nth_bit64(todo, __popc(idle8 & ((1u << g) - 1u)));              // (-1 when the rays run out before this group's turn)
-            const int my_rank = __popcll(todo & ((1ull << lane) - 1ull));
-            if (((todo >> lane) & 1ull) != 0ull && my_rank < n) my_group = nth_bit64((unsigned long long)idle8, my_rank);
-            for (int k = 0; k < n; ++k) todo &= todo - 1ull;
-            const int src4 = (owner >= 0 ? owner : lane) << 2;
-            const F3 nro = mk(bperm_f(src4, ln.ro.x), bperm_f(src4, ln.ro.y), bperm_f(src4, ln.ro.z));
-            const F3 nrd = mk(bperm_f(src4, ln.rd.x), bperm_f(src4, ln.rd.y), bperm_f(src4, ln.rd.z));
-            const F3 nri = mk(bperm_f(src4, ln.rinv.x), bperm_f(src4, ln.rinv.y), bperm_f(src4, ln.rinv.z));
-            const int nstate = __builtin_amdgcn_ds_bpermute(src4, ln.state);
-            if (owner >= 0) {
-                gro = nro; grd = nrd; grinv = nri; shadow = ANYHIT && nstate == ST_TRAV_SHADOW;
-                busy = true; node = 0; gsp = 0; guard = 0;
-                gclosest = kTMax; gcull = kTMax; ghit = -1; gtie = 0; gfail = 0;
-            }
-        }
-        if (!wave_any(busy)) break;
-        if (busy) {
-            if (node < 0 && gsp > 0) {                                   // pop attempt (every lane of the group reads the same entry)
-                --gsp;
-                lane_handoff_acquire();
-                const uint2 e = stk[gsp];
-                if (gcull > __uint_as_float(e.y)) node = (int)e.x;
-            }
-            if (node >= 0) {
-                if (CHECKED && (node >= S.num_wide || ++guard > kStepCap)) { flags |= node >= S.num_wide ? kFlagBadNodeRef : kFlagStepCap; node = -1; gsp = 0; gfail = 1; }
-            }
-            if (node >= 0) {
-                const float4* rec = S.wide + ((size_t)node * kWideChildren + j) * 2;
-                const float4 a = rec[0], b = rec[1];
-                const int ref = __float_as_int(b.z);
-                float te;
-                const bool hit = slab(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), gro, grinv, gcull, te) && ref != kWideEmpty;
-                const bool hit_int = hit && ref >= 0;
-                if (COUNT && j == 0) c[C_COOP_VISITS]++;
-                // the nearest hit internal child is next; the others are postponed
-                const uint32_t m_int = (uint32_t)(wave_ballot(hit_int) >> base) & 0xFFu;
-                const float tmin = group8_min(hit_int ? te : kTMax);
-                const uint32_t m_win = (uint32_t)(wave_ballot(hit_int && te == tmin) >> base) & 0xFFu;
-                const int win = m_win ? __builtin_ctz(m_win) : j;
-                const int next = __builtin_amdgcn_ds_bpermute((base + win) << 2, ref);
-                const uint32_t m_push = m_win ? m_int & ~(1u << win) : 0u;
-                const int n_push = __popc(m_push);
-                int first = 0, count = 0;
-                if (gsp + n_push > kCoopStack) { gfail = 1; node = -1; gsp = 0; }                           // (group-uniform) the ray goes back to its owner untouched
-                else {
-                    if (hit_int && j != win) stk[gsp + __popc(m_push & ((1u << j) - 1u))] = make_uint2((uint32_t)ref, __float_as_uint(te));
-                    lane_handoff_release();
-                    gsp += n_push;
-                    node = m_win ? next : -1;
-                    // leaves among the hit children: their lanes intersect them now
-                    if (hit && ref < 0) {
-                        first = leaf_payload(ref);
-                        count = leaf_code(ref) + 1;
-                        if (count == 8) {
-                            if (CHECKED && first >= S.num_big_leaves) { flags |= kFlagBadBigLeaf; first = 0; count = 0; }
-                            else { const int2 bl = S.big_leaves[first]; first = bl.x; count = bl.y; }
-                        }
-                        if (CHECKED && (first < 0 || first + ((count + 1) >> 1) > S.num_tri_pairs)) { flags |= kFlagBadTriSlot; count = 0; }
-                    }
-                }
-                float lt = gclosest, lu = 0.0f, lv = 0.0f;
-                int lslot = -1, ltie = 0;
-                const bool had = ghit >= 0;
-                for (int i = 0; wave_any(i < count); i += 2) {
-                    if (i < count) {
-                        const int pair = first + (i >> 1);
-                        v2f t, u, v;
-                        bool ok_a, ok_b;
-                        moller_trumbore_pair(S.tri_pairs + (size_t)pair * 5, gro, grd, t, u, v, ok_a, ok_b);
-                        if (COUNT) c[C_TRI_TESTS] += i + 1 < count ? 2 : 1;
-                        if (ok_a && !(t.x > lt)) { ltie = (t.x == lt && (had || lslot >= 0)) ? 1 : 0; lt = t.x; lslot = pair * 2; lu = u.x; lv = v.x; }
-                        if (ok_b && !(t.y > lt) && !(shadow && lslot >= 0)) { ltie = (t.y == lt && (had || lslot >= 0)) ? 1 : 0; lt = t.y; lslot = pair * 2 + 1; lu = u.y; lv = v.y; }
-                        if (shadow && lslot >= 0) count = 0;
-                    }
-                }
-                // merge, in lane order
-                bool cand = lslot >= 0;
-                for (;;) {
-                    const unsigned long long cm = wave_ballot(cand);
-                    if (!cm) break;
-                    const uint32_t m = (uint32_t)(cm >> base) & 0xFFu;
-                    const int w = m ? __builtin_ctz(m) : j;
-                    const int a4 = (base + w) << 2;
-                    const float ct = bperm_f(a4, lt), cu = bperm_f(a4, lu), cv = bperm_f(a4, lv);
-                    const int cs = __builtin_amdgcn_ds_bpermute(a4, lslot), ctie = __builtin_amdgcn_ds_bpermute(a4, ltie);
-                    if (m) {
-                        if (!(ct > gclosest)) {
-                            gtie = (ct == gclosest && ghit >= 0) ? 1 : ctie;
-                            gclosest = ct; gcull = ct * kCullRelax; ghit = cs; gu = cu; gv = cv;
-                        }
-                        if (j == w) cand = false;
-                    }
-                }
-                if (shadow && ghit >= 0) { node = -1; gsp = 0; }           // any-hit: the first accepted triangle ends the walk
-            }
-        }
-        // groups that have finished hand their answers back: the owner reads its group's first lane
-        const bool fin = busy && node < 0 && gsp == 0;
-        const unsigned long long fin_m = wave_ballot(fin);
-        if (fin_m != 0ull) {
-            const bool mine = my_group >= 0 && ((fin_m >> (my_group * kWideChildren)) & 1ull) != 0ull;
-            const int from4 = (mine ? my_group * kWideChildren : lane) << 2;
-            const float rc = bperm_f(from4, gclosest), ru = bperm_f(from4, gu), rv = bperm_f(from4, gv);
-            const int rhit = __builtin_amdgcn_ds_bpermute(from4, ghit), rbits = __builtin_amdgcn_ds_bpermute(from4, gtie | (gfail << 1));
-            if (mine) {
-                my_group = -1;
-                if (rbits & 2) { ln.aux |= kNoCoop; if (COUNT) c[C_COOP_OVERFLOWS]++; }
-                else {
-                    ln.closest = rc; ln.cull = rc * ln.relax; ln.hit_slot = rhit; ln.hit_u = ru; ln.hit_v = rv;
-                    ln.aux = (rbits & 1) ? (ln.aux | kTie) : (ln.aux & ~kTie);
-                    ln.cur = kRefNone; ln.sp = 0;
-                    ln.state -= (ST_TRAV_CLOSEST - ST_SHADE);
-                    if (COUNT) { c[C_COOP_RAYS]++; if (rhit >= 0) c[C_HIT_UPDATES]++; }
-                }
-            }
-            if (fin) busy = false;
-        }
-    }
-}
-
 // Node-loop iterations per look at the loop's votes (1: +1.4 % time, 3: no better than 2; profiles/r03/ab_node_loop_unroll.jsonl).
 constexpr int kNodeUnroll = 2;
 
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false, bool LEAN = false, bool COOP = false>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool PROBE, bool BATCH = false, bool LEAN = false>
 __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const DeviceScene& S = args.scene;
     __shared__ uint2 lds_stack[kWavesPerBlock][K + 1][64];       // entry K is a dump slot, see the node visit
@@ -271,7 +102,6 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
     const uint32_t glane = blockIdx.x * blockDim.x + threadIdx.x;
 
     __shared__ float lds_pend[kPendWords][kPendStride];
-    __shared__ uint2 lds_coop[COOP ? kWavesPerBlock : 1][COOP ? 8 * kCoopStack : 1];          // COOP: the groups' stacks of the cooperative walk (coop_walk)
     Lane ln;
     ln.pend = &lds_pend[0][threadIdx.x];
     ln.aux = (uint32_t)lane;
@@ -339,12 +169,6 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
         // other phase.  Switch when the first exceeds the second (the ratios are the relative lengths of the phases' code).
         // Invariant used for the votes below: a lane that is not walking a ray has cur == kRefNone, so "walking" and its
         // refinements are single compares on `cur` (a vote on one compare is the compare's own mask, no extra VALU work).
-        if constexpr (COOP) {
-            if (args.coop) {
-                const unsigned long long fresh = wave_ballot(cur == S.accel_root_ref && sp == 0 && (ln.aux & (kOnRef | kNoCoop)) == 0u && state >= ST_TRAV_CLOSEST && state <= ST_TRAV_SHADOW);
-                if (fresh != 0ull && __popcll(wave_ballot(cur != kRefNone)) <= args.coop) coop_walk<COUNT, CHECKED, ANYHIT>(ln, S, c, flags, &lds_coop[wave][0], fresh, lane);
-            }
-        }
         for (int wait_waste = 0;;) {
             const int n_walk = __popcll(wave_ballot(cur != kRefNone));
             if (n_walk == 0) break;
@@ -543,11 +367,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& args) {
 
 // LEAN (path_machine.h): the instantiation for scenes of Lambertian triangles only, chosen by the host from what upload found in the scene.  Production builds only:
 // the counting and checked builds are the general code.
-// COOP: the instantiation that also holds the cooperative walk (coop_walk) -- what a launch that the longest chains bound uses (device_api.hip: a rank's share of a frame);
-// the other launches run the kernels without it, whose registers and LDS it would cost.  The counting and checked builds always hold it.
-template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool LEAN = false, bool COOP = false>
+template <int K, bool COUNT, bool CHECKED, bool ANYHIT, int RNGMODE, bool LEAN = false>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) DSRT_WAVES_ATTR dsrt_render_kernel(const RenderArgs args) {
-    render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false, false, LEAN, COOP>(args);
+    render_body<K, COUNT, CHECKED, ANYHIT, RNGMODE, false, false, LEAN>(args);
 }
 
 // Batch launch: many frames of one scene as one pool of work (path_machine.h, ST_FETCH).
@@ -879,18 +701,15 @@ __global__ void dsrt_resolve_kernel(const unsigned long long* __restrict__ sums,
 template <int K, int RNGMODE>
 static hipError_t launch_k(const RenderArgs& a, int blocks, bool count, bool checked, bool anyhit, bool lean, hipStream_t stream) {
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
-    constexpr bool C = RNGMODE == 0;                      // the counting / checked builds of rng_mode 0 hold the cooperative walk (inert unless RenderArgs::coop > 0)
-    if (count) {
-        if (anyhit) hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, true, RNGMODE, false, C>), grid, block, 0, stream, a);
-        else        hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, false, RNGMODE, false, C>), grid, block, 0, stream, a);
+    if (!count && !checked && lean) {
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE, true>), grid, block, 0, stream, a);
+    } else if (count) {
+        if (anyhit) hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, true, RNGMODE>), grid, block, 0, stream, a);
+        else        hipLaunchKernelGGL((dsrt_render_kernel<K, true, true, false, RNGMODE>), grid, block, 0, stream, a);
     } else if (checked) {
-        hipLaunchKernelGGL((dsrt_render_kernel<K, false, true, true, RNGMODE, false, C>), grid, block, 0, stream, a);
-    } else if (C && a.coop > 0) {
-        if (lean) hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE, true, C>), grid, block, 0, stream, a);
-        else      hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE, false, C>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, true, true, RNGMODE>), grid, block, 0, stream, a);
     } else {
-        if (lean) hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE, true>), grid, block, 0, stream, a);
-        else      hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((dsrt_render_kernel<K, false, false, true, RNGMODE>), grid, block, 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -37,7 +37,7 @@ const char* dsrt_last_error(void);
  * refused; dsrt_selftest_devkat, dsrt_microbench_valu; 5 = DsrtRenderDesc.math_mode appended;
  * 6 = dsrt_host_scene_add_texture_file; 7 = round 4: dsrt_microbench_copy, dsrt_sizeof, dsrt_dev_set_experiment, dsrt_selftest_poke_node_word, dsrt_ctx_set_certified_tree, DsrtStats grew).  dsrt_abi_version() returns the value the library was compiled with;
  * bindings parse this line (capi.header_abi_version) and compare. */
-#define DSRT_ABI_VERSION 8
+#define DSRT_ABI_VERSION 7
 int dsrt_abi_version(void);
 /* sizeof of the structs that cross this ABI, as the LIBRARY was compiled: a binding that mirrors them by hand (ctypes, cgo, JNA ...) compares its own sizes with
  * these at load time, so that a struct that grew in the header and the library but not in the binding is refused instead of silently mis-laid.  0 = unknown. */
@@ -287,9 +287,6 @@ typedef struct DsrtStats {
     /* counting build, ms after the first wave started: the heavy / the light work queue handed out its last item, the last wave left */
     float    heavy_queue_empty_ms, light_queue_empty_ms, last_wave_exit_ms;
     int      certified_tree_used;   /* 1: the rays of this launch started on the certified second tree (dsrt_ctx_set_certified_tree) */
-    /* counting build, certified second tree: rays a wave with few rays left walked with eight lanes each on the tree's wide form (render_kernel.hip: coop_walk),
-     * the wide nodes those walks visited, and rays given back to the ordinary walk because a group's stack was full */
-    uint64_t coop_rays, coop_visits, coop_overflows;
 } DsrtStats;
 
 /* Number of bytes of the compact per-shard output of dsrt_render for this desc (rgb8) and the number of
