@@ -702,6 +702,9 @@ static int render_impl(DsrtContext* ctx, const DsrtRenderDesc* desc, uint8_t* d_
     // Walks of the second tree are a third shorter, so an advance pass is dearer against a node iteration than on the reference tree: the traverse phase stays three times
     // longer before it yields (interleaved medians, near frame: 760 -> 741 ms in rng_mode 0, 734 -> 701 in rng_mode 1; the reference walk gains nothing from it).
     if (a.accel && desc->tune[0] <= 0) a.min_walk_iters = 192;
+    // ... and its leaves come sooner: the node loop yields to the leaf pass at 0.6 parked lane-slots per descending lane instead of 1.0 (rng_mode 0: near frame -0.5 ... -1.1 %,
+    // frame 85 -5 %, frame 92 -2 %, one of 8 shares -1.6 %, far frames unchanged; rng_mode 1 loses 1 % and keeps 1.0: profiles/r04/ab_leaf_ratio_*.jsonl).
+    if (a.accel && desc->rng_mode == 0 && desc->tune[2] <= 0) a.leaf_ratio4 = 6;
     a.helpers = (flags & DSRT_TUNE_NO_HELPERS) ? 0 : 1;
     a.steal = ((flags & DSRT_TUNE_NO_STEALING) ? 0 : 1) | (((xp & (1u << 27)) && desc->collect_counters) ? 8 : 0);      // (8: timing image, counting build)
     // rng_mode 0: waves that hold a pixel of a heavy tile get issue priority over waves that only hold background pixels (render_body).
